@@ -1,0 +1,59 @@
+"""ctypes binding of libframepack_hip.so (C ABI: include/framepack_hip.h).
+
+The library is built in-tree by `make -C framepack_amd/csrc` (or `__graft_entry__.build()`).
+There is NO fallback: if the shared object is missing or a symbol is absent, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libframepack_hip.so")
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes, exactly the declarations of include/framepack_hip.h
+SIGNATURES = {
+    "fp_abi_version": [],
+    "fp_attn_fwd_bf16": [P, P, P, P, L, L, L, L, P, I, I, I, I, I, F, P],
+    "fp_qk_rmsnorm_rope_bf16": [P, P, L, I, I, I, P, P, P, P, P, I, F, P],
+    "fp_layernorm_modulate_bf16": [P, L, P, P, P, L, I, I, F, P],
+    "fp_gate_residual_bf16": [P, L, P, L, P, I, I, P],
+    "fp_silu_gemv_bf16": [P, P, P, P, I, I, I, P],
+    "fp_rel_l1_bf16": [P, P, L, P, P],
+    "fp_gemm_bf16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
+}
+
+_lib = None
+
+
+class FramepackHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly if it is not there (no CPU path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FramepackHipError(
+            f"{LIB_PATH} not found: build it with `make -C framepack_amd/csrc` "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def check(err: int, what: str) -> None:
+    if err == 0:
+        return
+    if err == 1:
+        raise ValueError(f"{what}: argument rejected by libframepack_hip (hipErrorInvalidValue)")
+    raise FramepackHipError(f"{what}: HIP error {err}")

@@ -1,0 +1,183 @@
+"""Tensor-level wrappers over the C ABI (include/framepack_hip.h).
+
+torch is used for device memory and the current stream only: every op hands raw pointers, shapes and
+strides to libframepack_hip.so.  CPU tensors are rejected: there is no fallback path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+BF16 = torch.bfloat16
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(*ts: Optional[torch.Tensor]) -> None:
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("framepack_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows2d(t: torch.Tensor):
+    """View a [.., rows, cols] tensor whose leading dims are 1 as (ptr, rows, cols, row_stride)."""
+    if t.dim() > 2:
+        t = t.reshape(-1, t.shape[-1]) if t.is_contiguous() else t.squeeze(0)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"expected a [rows, cols] tensor with unit inner stride, got {tuple(t.shape)} / {t.stride()}")
+    return t, t.shape[0], t.shape[1], t.stride(0)
+
+
+def layernorm_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, eps: float = 1e-6,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K3: LN(x) * (1 + scale) + shift.  x [rows, cols] (row-strided ok), scale/shift [cols]."""
+    _dev(x, scale, shift, out)
+    x2, rows, cols, xs = _rows2d(x)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=BF16, device=x.device)
+    o2, orows, ocols, os_ = _rows2d(out)
+    assert x.dtype == BF16 and out.dtype == BF16 and (orows, ocols) == (rows, cols)
+    scale = scale.reshape(-1).contiguous()
+    shift = shift.reshape(-1).contiguous()
+    assert scale.numel() == cols and shift.numel() == cols and scale.dtype == BF16 and shift.dtype == BF16
+    _lib.check(_lib.load().fp_layernorm_modulate_bf16(x2.data_ptr(), xs, scale.data_ptr(), shift.data_ptr(),
+                                                      o2.data_ptr(), os_, rows, cols, eps, _stream(x)),
+               "fp_layernorm_modulate_bf16")
+    return out
+
+
+def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
+    """K4: x += gate * y in place."""
+    _dev(x, y, gate)
+    x2, rows, cols, xs = _rows2d(x)
+    y2, yr, yc, ys = _rows2d(y)
+    gate = gate.reshape(-1).contiguous()
+    assert (yr, yc) == (rows, cols) and gate.numel() == cols
+    assert x.dtype == BF16 and y.dtype == BF16 and gate.dtype == BF16
+    _lib.check(_lib.load().fp_gate_residual_bf16(x2.data_ptr(), xs, y2.data_ptr(), ys, gate.data_ptr(), rows, cols,
+                                                 _stream(x)), "fp_gate_residual_bf16")
+    return x
+
+
+def qk_rmsnorm_rope_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor,
+                     rope: Optional[torch.Tensor], rope_rows: int, heads: int, eps: float = 1e-6,
+                     wq_txt: Optional[torch.Tensor] = None, wk_txt: Optional[torch.Tensor] = None) -> None:
+    """K2: in-place RMSNorm(q), RMSNorm(k) per head (+RoPE on rows < rope_rows).
+    q, k: [rows, heads*128] views sharing one row stride."""
+    _dev(q, k, wq, wk, rope, wq_txt, wk_txt)
+    q2, rows, cols, qs = _rows2d(q)
+    k2, kr, kc, ks = _rows2d(k)
+    assert (kr, kc) == (rows, cols) and qs == ks and cols == heads * 128
+    assert q.dtype == BF16 and k.dtype == BF16
+    for w in (wq, wk, wq_txt, wk_txt):
+        assert w is None or (w.dtype == BF16 and w.numel() == 128 and w.is_contiguous())
+    if rope_rows > 0:
+        assert rope is not None and rope.dtype == torch.float32 and rope.is_contiguous()
+        assert rope.shape[-1] == 256 and rope.numel() >= rope_rows * 256
+    _lib.check(_lib.load().fp_qk_rmsnorm_rope_bf16(q2.data_ptr(), k2.data_ptr(), qs, rows, heads, 128,
+                                                   wq.data_ptr(), wk.data_ptr(), _ptr(wq_txt), _ptr(wk_txt),
+                                                   _ptr(rope), rope_rows, eps, _stream(q)),
+               "fp_qk_rmsnorm_rope_bf16")
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
+              cu_seqlens: Optional[torch.Tensor] = None, max_seqlen: Optional[int] = None,
+              scale: Optional[float] = None) -> torch.Tensor:
+    """K1: non-causal flash attention.  q,k,v: [tokens, heads*128] views (row-strided ok).
+    cu_seqlens: int32 device [nseg+1] for varlen, None for one segment.  out may alias q."""
+    _dev(q, k, v, out, cu_seqlens)
+    q2, rows, cols, qs = _rows2d(q)
+    k2, _, _, ks = _rows2d(k)
+    v2, _, _, vs = _rows2d(v)
+    assert cols == heads * 128 and k2.shape == q2.shape and v2.shape == q2.shape
+    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16
+    if out is None:
+        out = torch.empty((rows, cols), dtype=BF16, device=q.device)
+    o2, orows, ocols, os_ = _rows2d(out)
+    assert (orows, ocols) == (rows, cols) and out.dtype == BF16
+    nseg = 1
+    if cu_seqlens is not None:
+        assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous()
+        nseg = cu_seqlens.numel() - 1
+    if max_seqlen is None:
+        max_seqlen = rows
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    _lib.check(_lib.load().fp_attn_fwd_bf16(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o2.data_ptr(), qs, ks, vs, os_,
+                                            _ptr(cu_seqlens), nseg, max_seqlen, rows, heads, 128, scale, _stream(q)),
+               "fp_attn_fwd_bf16")
+    return out
+
+
+def silu_gemv(t: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], apply_silu: bool = True,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K7: Linear(SiLU(t)) for a single vector t [in]; weight [out, in]."""
+    _dev(t, weight, bias, out)
+    t = t.reshape(-1).contiguous()
+    assert weight.dim() == 2 and weight.is_contiguous() and weight.shape[1] == t.numel()
+    assert t.dtype == BF16 and weight.dtype == BF16 and (bias is None or bias.dtype == BF16)
+    n = weight.shape[0]
+    if out is None:
+        out = torch.empty((n,), dtype=BF16, device=t.device)
+    assert out.numel() == n and out.is_contiguous() and out.dtype == BF16
+    _lib.check(_lib.load().fp_silu_gemv_bf16(t.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(),
+                                             t.numel(), n, int(apply_silu), _stream(t)), "fp_silu_gemv_bf16")
+    return out
+
+
+def rel_l1(a: torch.Tensor, b: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K10: returns device float32 [2] = (sum|a-b|, sum|b|)."""
+    _dev(a, b, acc)
+    assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and a.dtype == BF16 and b.dtype == BF16
+    if acc is None:
+        acc = torch.empty((2,), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().fp_rel_l1_bf16(a.data_ptr(), b.data_ptr(), a.numel(), acc.data_ptr(), _stream(a)),
+               "fp_rel_l1_bf16")
+    return acc
+
+
+EPI_BIAS, EPI_GELU, EPI_GELU_FROM, EPI_GATE_RESIDUAL = 0, 1, 2, 3
+
+
+def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
+         epilogue: int = EPI_BIAS, gelu_from: int = 0, resid: Optional[torch.Tensor] = None,
+         gate: Optional[torch.Tensor] = None, a2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K5: out = epilogue(a @ weight.T + bias).  a [M,K] (row-strided ok), weight [N,K] (row-strided ok).
+    a2: optional second K segment [M,K2] with the same row stride as a (K = K1 + K2)."""
+    _dev(a, weight, bias, out, resid, gate, a2)
+    a_, M, K1, lda = _rows2d(a)
+    w_, N, K, ldw = _rows2d(weight)
+    k1 = K1
+    if a2 is not None:
+        a2_, M2, K2, lda2 = _rows2d(a2)
+        assert M2 == M and lda2 == lda and K1 + K2 == K
+    else:
+        assert K1 == K, f"A has K={K1}, weight has K={K}"
+    assert a.dtype == BF16 and weight.dtype == BF16 and (bias is None or (bias.dtype == BF16 and bias.numel() == N))
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a.device)
+    o_, Mo, No, ldc = _rows2d(out)
+    assert (Mo, No) == (M, N) and out.dtype == BF16
+    ldr = 0
+    if epilogue == EPI_GATE_RESIDUAL:
+        r_, Mr, Nr, ldr = _rows2d(resid)
+        assert (Mr, Nr) == (M, N) and resid.dtype == BF16
+        gate = gate.reshape(-1).contiguous()
+        assert gate.numel() == N and gate.dtype == BF16
+        rptr, gptr = r_.data_ptr(), gate.data_ptr()
+    else:
+        rptr, gptr = None, None
+    _lib.check(_lib.load().fp_gemm_bf16(a_.data_ptr(), lda, None if a2 is None else a2_.data_ptr(), k1, w_.data_ptr(), ldw,
+                                        _ptr(bias), o_.data_ptr(), ldc, M, N, K, epilogue, gelu_from, rptr, ldr, gptr,
+                                        _stream(a)), "fp_gemm_bf16")
+    return out

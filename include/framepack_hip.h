@@ -1,0 +1,87 @@
+/* framepack_hip.h - C ABI of libframepack_hip.so (gfx950 / MI355X).
+ *
+ * The reference (wongfei2009/FramePack) has NO native interface for this path: its boundary is the
+ * Python nn.Module `HunyuanVideoTransformer3DModelPacked`.  This library is the layer
+ * a binding sits on: one entry point per fused kernel, raw device pointers + shapes + a hipStream_t,
+ * no torch types.  Each declaration cites the reference code the kernel replaces
+ * (paths relative to the reference root).  The Python host mirror is framepack_amd/model.py; the ctypes
+ * binding a maintainer would add to the reference is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch caching allocator), bf16 unless noted;
+ *   - "row stride" is in ELEMENTS; rows are token rows; inner dimensions are contiguous;
+ *   - pointers must be 16-byte aligned and strides multiples of 8 elements unless noted;
+ *   - `stream` is a hipStream_t (NULL = default stream); calls are asynchronous and allocate nothing;
+ *   - return value: 0 on success, otherwise a hipError_t (hipErrorInvalidValue = 1 for a rejected
+ *     argument: nothing was launched).
+ */
+#ifndef FRAMEPACK_HIP_H
+#define FRAMEPACK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library/ABI version (bumped when a signature changes). */
+int fp_abi_version(void);
+
+/* K1  varlen flash-attention forward, non-causal, head_dim 128.
+ * Replaces diffusers_helper/models/hunyuan_video_packed.py:89-112 (attn_varlen_func; parity target is the
+ * SDPA branch :97).  q,k,v,o: [total_tokens, heads, 128]; segment s covers token rows
+ * cu_seqlens[s] .. cu_seqlens[s+1] (int32, device; the layout :63-77 builds), or pass NULL with nseg = 1
+ * for one segment over all rows (the B == 1 branch :927-932).  max_seqlen >= the longest segment.
+ * `o` may alias `q`.  o needs 8-byte alignment / stride % 4 only. */
+int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o,
+                     int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                     const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens,
+                     int heads, int head_dim, float softmax_scale, void* stream);
+
+/* K2  in-place RMSNorm over head_dim (=128) of q and k, then RoPE on token rows [0, rope_rows).
+ * Replaces diffusers_helper/dit_common.py:31-39 (RMSNorm_forward) + hunyuan_video_packed.py:80-86
+ * (apply_rotary_emb_transposed) + the cats of :180-181.  q,k: [rows, heads, 128] sharing row_stride.
+ * wq,wk: [128] norm weights; wq_txt,wk_txt: optional weights for rows >= rope_rows (norm_added_q/k of the
+ * double-stream blocks, :141-142), NULL = use wq/wk.  rope: fp32 [rope_rows, 256] = cos[128] | sin[128]
+ * per row (the table of :397-432).  Rounding points are the reference's. */
+int fp_qk_rmsnorm_rope_bf16(void* q, void* k, int64_t row_stride, int rows, int heads, int head_dim,
+                            const void* wq, const void* wk, const void* wq_txt, const void* wk_txt,
+                            const float* rope, int rope_rows, float eps, void* stream);
+
+/* K3  y = LayerNorm(x; no affine, eps) * (1 + scale) + shift,  x,y: [rows, cols], scale,shift: [cols].
+ * Replaces diffusers_helper/dit_common.py:9-10 + hunyuan_video_packed.py:453, 476, 502, 642-643.
+ * cols <= 4096. */
+int fp_layernorm_modulate_bf16(const void* x, int64_t x_row_stride, const void* scale, const void* shift,
+                               void* y, int64_t y_row_stride, int rows, int cols, float eps, void* stream);
+
+/* K4  x += gate * y,  x,y: [rows, cols], gate: [cols].
+ * Replaces hunyuan_video_packed.py:636-637, 649-650, 570-571. */
+int fp_gate_residual_bf16(void* x, int64_t x_row_stride, const void* y, int64_t y_row_stride,
+                          const void* gate, int rows, int cols, void* stream);
+
+/* K7  out[n] = sum_k W[n,k] * f(t[k]) + bias[n],  f = SiLU (apply_silu != 0) or identity.
+ * The batch-1 modulation GEMV: hunyuan_video_packed.py:451, 474, 500, 245 (Linear(SiLU(temb))).
+ * W: [out_dim, in_dim] row-major (nn.Linear layout), in_dim <= 4096; bias may be NULL. */
+int fp_silu_gemv_bf16(const void* t, const void* W, const void* bias, void* out,
+                      int in_dim, int out_dim, int apply_silu, void* stream);
+
+/* K10 TeaCache statistic: acc2[0] = sum |a - b| (difference rounded to bf16 first), acc2[1] = sum |b|.
+ * Replaces hunyuan_video_packed.py:957-958.  a,b: n bf16 elements (n % 8 == 0); acc2: 2 floats (device),
+ * zeroed by the call. */
+int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc2, void* stream);
+
+/* K5  C = epilogue(A . W^T + bias): the nn.Linear of every block (hunyuan_video_packed.py:119-121,
+ * 133-135, 154-156, 167-169, 552, 570 and diffusers FeedForward at :646-647).
+ *   A: [M, K] row stride lda;  W: [N, K] row-major (nn.Linear layout), row stride ldw;  C: [M, N] stride ldc.
+ *   epilogue: 0 = bias only; 1 = bias + tanh-GELU; 2 = bias + tanh-GELU on columns >= gelu_from only;
+ *             3 = C = R + gate * (A.W^T + bias)  with R: [M, N] stride ldr (may alias C), gate: [N].
+ *   A may be given as two column segments (a2 != NULL): K = k1 + k2, the second segment read from a2
+ *   (same row stride) - the cat([attn, mlp]) of :569 without the copy. */
+int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
+                 const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
+                 const void* resid, int64_t ldr, const void* gate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRAMEPACK_HIP_H */

@@ -1,0 +1,239 @@
+"""Per-kernel parity: each HIP kernel (through the C ABI, via framepack_amd.ops) against the CPU oracle on
+the same seeded inputs.  Tolerances: outputs are bf16 (8 significand bits, rel. rounding 2^-9 = 2e-3), so
+elementwise kernels are held to rel-L2 <= 3e-3 and MFMA kernels (bf16 P / fp32 accumulate) to rel-L2 <= 5e-3
+against an fp64/fp32 reference computed from the SAME bf16 inputs; the north-star bound is 1e-2 per block."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from framepack_amd import ops  # noqa: E402
+from oracle import dit_oracle as O  # noqa: E402
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def randn(*shape, seed=0, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+# ------------------------------------------------------------------ K3
+@pytest.mark.parametrize("rows,cols", [(1, 256), (5, 256), (777, 3072), (130, 4096), (3, 8), (19385, 3072)])
+def test_layernorm_modulate(rows, cols):
+    x, sc, sh = randn(rows, cols, seed=1, scale=2.0) + 0.5, randn(cols, seed=2, scale=0.3), randn(cols, seed=3)
+    ref = O.layer_norm(x.float()) * (1 + sc.float()) + sh.float()
+    got = ops.layernorm_modulate(x.to(DEV), sc.to(DEV), sh.to(DEV))
+    assert got.dtype == BF and rel_l2(got, ref) < 3e-3
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_layernorm_modulate_strided_views():
+    big = randn(40, 1024, seed=4)
+    x = big[:, 256:512]
+    sc, sh = randn(256, seed=5), randn(256, seed=6)
+    outbuf = torch.zeros(40, 768, dtype=BF, device=DEV)
+    ops.layernorm_modulate(big.to(DEV)[:, 256:512], sc.to(DEV), sh.to(DEV), out=outbuf[:, 512:768])
+    ref = O.layer_norm(x.float()) * (1 + sc.float()) + sh.float()
+    assert rel_l2(outbuf[:, 512:768], ref) < 3e-3
+    assert outbuf[:, :512].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ K4
+@pytest.mark.parametrize("rows,cols", [(1, 8), (333, 256), (2000, 3072)])
+def test_gate_residual(rows, cols):
+    x, y, g = randn(rows, cols, seed=1), randn(rows, cols, seed=2), randn(cols, seed=3)
+    ref = x.float() + g.float() * y.float()
+    xd = x.to(DEV)
+    ops.gate_residual_(xd, y.to(DEV), g.to(DEV))
+    assert rel_l2(xd, ref) < 3e-3
+
+
+# ------------------------------------------------------------------ K2
+@pytest.mark.parametrize("rows,rope_rows,heads,two_w", [(50, 50, 2, False), (300, 211, 3, True), (64, 0, 24, False),
+                                                        (1408 + 766, 1408, 2, True)])
+def test_qk_rmsnorm_rope(rows, rope_rows, heads, two_w):
+    d = heads * 128
+    buf = randn(rows, 3 * d + 64, seed=7)                      # q | k | v | pad  (row-strided views)
+    wq, wk = 1 + 0.1 * randn(128, seed=8), 1 + 0.1 * randn(128, seed=9)
+    wq2, wk2 = (1 + 0.1 * randn(128, seed=10), 1 + 0.1 * randn(128, seed=11)) if two_w else (None, None)
+    g = torch.Generator("cpu").manual_seed(12)
+    ang = torch.rand(max(rope_rows, 1), 128, generator=g) * 6.28
+    rope = torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous()
+
+    def ref_one(x, w, w2):
+        x = x.reshape(1, rows, heads, 128)
+        img = O.apply_rope(O.rms_norm(x[:, :rope_rows], w), rope[:rope_rows].unsqueeze(0))
+        txt = O.rms_norm(x[:, rope_rows:], w2 if w2 is not None else w)
+        return torch.cat([img, txt], dim=1).reshape(rows, d)
+
+    q_ref = ref_one(buf[:, :d], wq, wq2)
+    k_ref = ref_one(buf[:, d:2 * d], wk, wk2)
+    bd = buf.to(DEV)
+    ops.qk_rmsnorm_rope_(bd[:, :d], bd[:, d:2 * d], wq.to(DEV), wk.to(DEV), rope.to(DEV), rope_rows, heads,
+                         wq_txt=None if wq2 is None else wq2.to(DEV), wk_txt=None if wk2 is None else wk2.to(DEV))
+    assert rel_l2(bd[:, :d], q_ref) < 2e-3 and rel_l2(bd[:, d:2 * d], k_ref) < 2e-3
+    # same rounding points as the reference: at most 1 bf16 ulp away, and almost everywhere identical
+    diff = (bd[:, :d].float().cpu() - q_ref.float()).abs()
+    assert (diff <= q_ref.float().abs() * 2 ** -7 + 1e-6).all()
+    assert (diff == 0).float().mean().item() > 0.97
+    assert torch.equal(bd[:, 2 * d:].cpu(), buf[:, 2 * d:])     # v and pad untouched
+
+
+# ------------------------------------------------------------------ K7 / K10
+@pytest.mark.parametrize("n_in,n_out,silu", [(256, 1536, True), (3072, 18432, True), (3072, 100, False), (4096, 7, True)])
+def test_silu_gemv(n_in, n_out, silu):
+    t, W, b = randn(n_in, seed=1), randn(n_out, n_in, seed=2, scale=1 / math.sqrt(n_in)), randn(n_out, seed=3)
+    a = torch.nn.functional.silu(t) if silu else t              # bf16 SiLU, as the reference
+    ref = a.float() @ W.float().T + b.float()
+    got = ops.silu_gemv(t.to(DEV), W.to(DEV), b.to(DEV), apply_silu=silu)
+    assert rel_l2(got, ref) < 4e-3
+
+
+def test_rel_l1():
+    a, b = randn(1000, 3072, seed=1), randn(1000, 3072, seed=2)
+    acc = ops.rel_l1(a.to(DEV), b.to(DEV)).cpu()
+    d = (a - b).abs().float().sum().item()                      # bf16 subtraction, as the reference
+    m = b.float().abs().sum().item()
+    assert abs(acc[0].item() - d) / d < 1e-4 and abs(acc[1].item() - m) / m < 1e-4
+
+
+# ------------------------------------------------------------------ K5
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1, 8, 64), (300, 768, 256), (1408, 1792, 256), (777, 3072, 3072),
+                                   (513, 264, 1280)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_gemm_epilogues(M, N, K, epi):
+    a, w, b = randn(M, K, seed=1), randn(N, K, seed=2, scale=1 / math.sqrt(K)), randn(N, seed=3)
+    lin = a.float() @ w.float().T + b.float()
+    gelu = torch.nn.functional.gelu(lin, approximate="tanh")
+    kw = {}
+    if epi == 0:
+        ref = lin
+    elif epi == 1:
+        ref = gelu
+    elif epi == 2:
+        gf = (N // 2) // 4 * 4
+        ref = torch.cat([lin[:, :gf], gelu[:, gf:]], dim=1)
+        kw = dict(gelu_from=gf)
+    else:
+        r, g = randn(M, N, seed=4), randn(N, seed=5)
+        ref = r.float() + g.float() * lin
+        kw = dict(resid=r.to(DEV), gate=g.to(DEV))
+    got = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=epi, **kw)
+    assert got.shape == (M, N) and rel_l2(got, ref) < 4e-3
+
+
+def test_gemm_strided_two_segment_and_inplace_residual():
+    M, N, K1, K2 = 389, 512, 256, 1024
+    buf = randn(M, 3 * 256 + K2 + 128, seed=1)                  # [k | v | o | mlp | pad]
+    w, b = randn(N, K1 + K2, seed=2, scale=0.03), randn(N, seed=3)
+    x, g = randn(M, N, seed=4), randn(N, seed=5)
+    bd = buf.to(DEV)
+    a_cat = torch.cat([buf[:, 512:768], buf[:, 768:768 + K2]], dim=1)
+    ref = x.float() + g.float() * (a_cat.float() @ w.float().T + b.float())
+    # (a) contiguous column range of a row-strided buffer
+    xd = x.to(DEV)
+    ops.gemm(bd[:, 512:768 + K2], w.to(DEV), b.to(DEV), out=xd, epilogue=3, resid=xd, gate=g.to(DEV))
+    assert rel_l2(xd, ref) < 4e-3
+    # (b) two explicit K segments
+    xd2 = x.to(DEV)
+    ops.gemm(bd[:, 512:768], w.to(DEV), b.to(DEV), out=xd2, epilogue=3, resid=xd2, gate=g.to(DEV),
+             a2=bd[:, 768:768 + K2])
+    assert rel_l2(xd2, ref) < 4e-3
+
+
+def test_gemm_rejects_bad_arguments():
+    a, w = randn(4, 100, seed=1).to(DEV), randn(8, 100, seed=2).to(DEV)   # K % 64 != 0
+    with pytest.raises(ValueError):
+        ops.gemm(a, w, None)
+    with pytest.raises(RuntimeError):
+        ops.gemm(randn(4, 64), randn(8, 64), None)                        # CPU tensors: no fallback
+
+
+# ------------------------------------------------------------------ K1
+def attn_ref(q, k, v, heads):
+    S = q.shape[0]
+    return O.attention_reference_f64(q.view(S, heads, 128), k.view(S, heads, 128), v.view(S, heads, 128)).reshape(S, -1)
+
+
+@pytest.mark.parametrize("S,heads", [(1, 1), (63, 2), (64, 1), (65, 3), (255, 1), (256, 2), (257, 1), (777, 3),
+                                     (1408 + 766, 2), (2 * 256 + 64, 24)])
+def test_attention_single_segment(S, heads):
+    d = heads * 128
+    q, k, v = randn(S, d, seed=1), randn(S, d, seed=2), randn(S, d, seed=3)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert rel_l2(got, attn_ref(q, k, v, heads)) < 5e-3
+
+
+def test_attention_strided_fused_buffer_and_alias():
+    """q,k,v as column ranges of one [S, k|v|q|mlp] buffer (the single-stream layout); o written over q."""
+    S, heads = 900, 2
+    d = heads * 128
+    buf = randn(S, 3 * d + 512, seed=5)
+    ref = attn_ref(buf[:, 2 * d:3 * d].contiguous(), buf[:, :d].contiguous(), buf[:, d:2 * d].contiguous(), heads)
+    bd = buf.to(DEV)
+    ops.attention(bd[:, 2 * d:3 * d], bd[:, :d], bd[:, d:2 * d], heads, out=bd[:, 2 * d:3 * d])
+    assert rel_l2(bd[:, 2 * d:3 * d], ref) < 5e-3
+    assert torch.equal(bd[:, :2 * d].cpu(), buf[:, :2 * d]) and torch.equal(bd[:, 3 * d:].cpu(), buf[:, 3 * d:])
+
+
+def test_attention_varlen_segments():
+    """cu_seqlens as ref hunyuan_video_packed.py:63-77 builds them: valid tokens and the padding tail of
+    each sample are separate segments; an empty segment is allowed."""
+    heads, d = 2, 256
+    cu = [0, 300, 517, 517, 1000, 1064]
+    S = cu[-1]
+    q, k, v = randn(S, d, seed=1), randn(S, d, seed=2), randn(S, d, seed=3)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads,
+                        cu_seqlens=torch.tensor(cu, dtype=torch.int32, device=DEV), max_seqlen=483)
+    for a, b in zip(cu[:-1], cu[1:]):
+        if b > a:
+            assert rel_l2(got[a:b], attn_ref(q[a:b], k[a:b], v[a:b], heads)) < 5e-3
+
+
+def test_attention_max_jump_forces_rescale_branch():
+    """Spike one key against every query in a late tile so the running max jumps there
+    (the data-dependent rescale branch), plus large-magnitude scores."""
+    S, heads = 640, 1
+    q, k, v = randn(S, 128, seed=1), randn(S, 128, seed=2), randn(S, 128, seed=3)
+    k[500] = (q[:64].float().mean(0) * 6).to(BF)
+    k[630] = (q[100:164].float().mean(0) * -9).to(BF)
+    q[7] = q[7] * 8
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    ref = attn_ref(q, k, v, heads)
+    assert torch.isfinite(got.float()).all()
+    assert rel_l2(got, ref) < 5e-3
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
+
+
+def test_attention_full_size_properties():
+    """BASELINE config 2 shape (S = 19385, 24 heads): size-independent properties + sampled rows vs fp64."""
+    S, heads = 19385, 24
+    d = heads * 128
+    g = torch.Generator(device=DEV).manual_seed(0)
+    q = torch.randn(S, d, generator=g, device=DEV).to(BF)
+    k = torch.randn(S, d, generator=g, device=DEV).to(BF)
+    v = torch.randn(S, d, generator=g, device=DEV).to(BF)
+    o = ops.attention(q, k, v, heads)
+    # (1) V = const -> O = const exactly up to bf16 rounding (softmax weights sum to 1; tail masking right)
+    o1 = ops.attention(q, k, torch.full_like(v, 0.75), heads)
+    assert (o1.float() - 0.75).abs().max().item() < 4e-3
+    # (2) permuting the keys/values leaves the output unchanged up to accumulation order
+    perm = torch.randperm(S, generator=g, device=DEV)
+    o2 = ops.attention(q, k[perm].contiguous(), v[perm].contiguous(), heads)
+    assert rel_l2(o2, o) < 4e-3
+    # (3) sampled query rows x 3 heads against the fp64 oracle
+    rows = torch.tensor([0, 1, 255, 256, 9000, 18399, 18400, 19200, 19384])
+    for h in (0, 11, 23):
+        sl = slice(h * 128, (h + 1) * 128)
+        qh, kh, vh = q[rows][:, sl].cpu().double(), k[:, sl].cpu().double(), v[:, sl].cpu().double()
+        p = torch.softmax(qh @ kh.T / math.sqrt(128.0), dim=-1)
+        assert rel_l2(o[rows][:, sl], p @ vh) < 6e-3
