@@ -1,0 +1,656 @@
+"""HunyuanVideoTransformer3DModelPacked on MI355X: host mirror of the reference's module interface.
+
+Same class name, constructor arguments, forward signature, state-dict key names, TeaCache attributes
+and error behaviour as ref diffusers_helper/models/hunyuan_video_packed.py:698-1062, so
+diffusers_helper/k_diffusion/wrapper.py:43 and framepack/worker.py drive it unchanged.  The arithmetic
+of the 60 transformer blocks runs in libframepack_hip.so (hand-written gfx950 kernels, C ABI in
+include/framepack_hip.h); torch provides device memory, the stream and the tiny step-level embedders.
+
+Data layout in HBM (B == 1, S = Si + St tokens, d = heads*128):
+  X   [S, d]      residual stream, image tokens first then [image-proj | text] tokens: the double-stream
+                  blocks use the two row ranges, the single-stream blocks the whole buffer (no cat/split)
+  N   [S, d]      LayerNorm+modulate output
+  Y   [S, 7d]     projection workspace: double blocks use [q|k|v] (3d) and the FF hidden (4d);
+                  single blocks the fused [k|v|q|mlp]; attention writes O over q, so the output
+                  projection reads [o] or [o|mlp] in place (no cat of ref :144-146, :165, :569)
+There is no CPU path: forward() raises if the inputs are not on a GPU or the library is missing.
+"""
+from __future__ import annotations
+
+import json
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import lib as _lib
+from . import ops
+from .packing import RopeCache, get_cu_seqlens, pad_to_multiple, patch_rows, unpatchify
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------------------------
+# parameter containers (names = the reference's / diffusers' state-dict names)
+# --------------------------------------------------------------------------------------------
+class _NormWeight(nn.Module):
+    """RMSNorm parameter holder (`norm_q.weight` ...); applied inside the fused K2 kernel."""
+
+    def __init__(self, dim: int, eps: float):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class _MLP2(nn.Module):
+    """linear_2(silu(linear_1(x))): TimestepEmbedding / PixArtAlphaTextProjection(act_fn='silu')."""
+
+    def __init__(self, d_in: int, d: int):
+        super().__init__()
+        self.linear_1 = nn.Linear(d_in, d)
+        self.linear_2 = nn.Linear(d, d)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class _ActProj(nn.Module):
+    def __init__(self, d_in: int, d_out: int):
+        super().__init__()
+        self.proj = nn.Linear(d_in, d_out)
+
+
+class _FeedForward(nn.Module):
+    """Parameter layout of diffusers FeedForward: net.0.proj, net.2 (net.1 is the dropout slot)."""
+
+    def __init__(self, d: int, mult: float):
+        super().__init__()
+        inner = int(d * mult)
+        self.net = nn.ModuleList([_ActProj(d, inner), nn.Identity(), nn.Linear(inner, d)])
+
+
+class _Attention(nn.Module):
+    """Parameter layout of diffusers Attention as the reference constructs it (ref :265-271, 519-530, 595-607)."""
+
+    def __init__(self, d: int, heads: int, head_dim: int, qk_norm: bool, added_kv: bool, pre_only: bool, eps=1e-6):
+        super().__init__()
+        self.heads = heads
+        self.to_q, self.to_k, self.to_v = nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d)
+        if qk_norm:
+            self.norm_q, self.norm_k = _NormWeight(head_dim, eps), _NormWeight(head_dim, eps)
+        if added_kv:
+            self.add_q_proj, self.add_k_proj, self.add_v_proj = nn.Linear(d, d), nn.Linear(d, d), nn.Linear(d, d)
+            if qk_norm:
+                self.norm_added_q, self.norm_added_k = _NormWeight(head_dim, eps), _NormWeight(head_dim, eps)
+            self.to_add_out = nn.Linear(d, d)
+        if not pre_only:
+            self.to_out = nn.ModuleList([nn.Linear(d, d), nn.Identity()])
+
+
+class _AdaLinear(nn.Module):
+    """`<name>.linear`: emb = Linear(SiLU(temb)) (ref :435-503, :234-248); evaluated by the K7 GEMV."""
+
+    def __init__(self, d: int, n_out: int):
+        super().__init__()
+        self.linear = nn.Linear(d, n_out)
+
+
+class HunyuanVideoTransformerBlock(nn.Module):          # ref :580-652
+    def __init__(self, heads: int, head_dim: int, mlp_ratio: float, qk_norm: str = "rms_norm"):
+        super().__init__()
+        d = heads * head_dim
+        self.norm1 = _AdaLinear(d, 6 * d)
+        self.norm1_context = _AdaLinear(d, 6 * d)
+        self.attn = _Attention(d, heads, head_dim, qk_norm == "rms_norm", added_kv=True, pre_only=False)
+        self.ff = _FeedForward(d, mlp_ratio)
+        self.ff_context = _FeedForward(d, mlp_ratio)
+
+
+class HunyuanVideoSingleTransformerBlock(nn.Module):    # ref :506-577
+    def __init__(self, heads: int, head_dim: int, mlp_ratio: float = 4.0, qk_norm: str = "rms_norm"):
+        super().__init__()
+        d = heads * head_dim
+        self.attn = _Attention(d, heads, head_dim, qk_norm == "rms_norm", added_kv=False, pre_only=True)
+        self.norm = _AdaLinear(d, 3 * d)
+        self.proj_mlp = nn.Linear(d, int(d * mlp_ratio))
+        self.proj_out = nn.Linear(d + int(d * mlp_ratio), d)
+
+
+class _RefinerBlock(nn.Module):                         # ref :251-298
+    def __init__(self, heads: int, head_dim: int, mlp_ratio: float):
+        super().__init__()
+        d = heads * head_dim
+        self.norm1 = nn.LayerNorm(d, eps=1e-6)
+        self.attn = _Attention(d, heads, head_dim, qk_norm=False, added_kv=False, pre_only=False)
+        self.norm2 = nn.LayerNorm(d, eps=1e-6)
+        self.ff = _FeedForward(d, mlp_ratio)
+        self.norm_out = _AdaLinear(d, 2 * d)
+
+
+class _TokenRefinerStack(nn.Module):
+    def __init__(self, heads, head_dim, n, mlp_ratio):
+        super().__init__()
+        self.refiner_blocks = nn.ModuleList([_RefinerBlock(heads, head_dim, mlp_ratio) for _ in range(n)])
+
+
+class _TimeTextEmbed(nn.Module):
+    def __init__(self, d, pooled_dim, guidance: bool):
+        super().__init__()
+        self.timestep_embedder = _MLP2(256, d)
+        if guidance:
+            self.guidance_embedder = _MLP2(256, d)
+        self.text_embedder = _MLP2(pooled_dim, d)
+
+
+def _sinusoid_256(t: torch.Tensor) -> torch.Tensor:
+    """Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): fp32 [cos | sin] (ref :195, 219)."""
+    f = torch.exp(-np.log(10000.0) * torch.arange(128, dtype=torch.float32, device=t.device) / 128)
+    ang = t[:, None].float() * f[None, :]
+    return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
+
+
+class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
+    """Text-context embedder: 512 padded tokens, 2 small blocks, once per step (< 0.3 % of the FLOPs).
+    Runs on library GEMMs/SDPA through torch (plain, unfused, tiny) - not part of the hand-written path."""
+
+    def __init__(self, in_channels, heads, head_dim, num_layers, mlp_ratio=4.0):
+        super().__init__()
+        d = heads * head_dim
+        self.heads = heads
+        self.time_text_embed = _TimeTextEmbed(d, in_channels, guidance=False)
+        self.proj_in = nn.Linear(in_channels, d)
+        self.token_refiner = _TokenRefinerStack(heads, head_dim, num_layers, mlp_ratio)
+
+    def forward(self, text, timestep, mask):
+        if mask is None:
+            pooled = text.mean(dim=1)
+        else:
+            mf = mask.float().unsqueeze(-1)
+            pooled = ((text * mf).sum(dim=1) / mf.sum(dim=1)).to(text.dtype)
+        temb = self.time_text_embed.timestep_embedder(_sinusoid_256(timestep).to(pooled.dtype)) \
+            + self.time_text_embed.text_embedder(pooled)
+        x = self.proj_in(text)
+        sa = None
+        if mask is not None:
+            B, L = mask.shape
+            m1 = mask.to(x.device).bool().view(B, 1, 1, L).expand(B, 1, L, L)
+            sa = (m1 & m1.transpose(2, 3)).clone()
+            sa[:, :, :, 0] = True                                      # ref :340
+        H = self.heads
+        for blk in self.token_refiner.refiner_blocks:
+            n1 = blk.norm1(x)
+            B, S, d = n1.shape
+            q = blk.attn.to_q(n1).view(B, S, H, -1).transpose(1, 2)
+            k = blk.attn.to_k(n1).view(B, S, H, -1).transpose(1, 2)
+            v = blk.attn.to_v(n1).view(B, S, H, -1).transpose(1, 2)
+            a = F.scaled_dot_product_attention(q, k, v, attn_mask=sa).transpose(1, 2).reshape(B, S, d)
+            a = blk.attn.to_out[0](a)
+            g_msa, g_mlp = blk.norm_out.linear(F.silu(temb)).chunk(2, dim=-1)
+            x = x + a * g_msa.unsqueeze(1)
+            ff = blk.ff.net[2](F.silu(blk.ff.net[0].proj(blk.norm2(x))))
+            x = x + ff * g_mlp.unsqueeze(1)
+        return x
+
+
+class ClipVisionProjection(nn.Module):                  # ref :655-663
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.up = nn.Linear(in_channels, out_channels * 3)
+        self.down = nn.Linear(out_channels * 3, out_channels)
+
+    def forward(self, x):
+        return self.down(F.silu(self.up(x)))
+
+
+class HunyuanVideoPatchEmbed(nn.Module):                # ref :666-669
+    def __init__(self, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+
+class HunyuanVideoPatchEmbedForCleanLatents(nn.Module):  # ref :672-677
+    def __init__(self, inner_dim):
+        super().__init__()
+        self.proj = nn.Conv3d(16, inner_dim, kernel_size=(1, 2, 2), stride=(1, 2, 2))
+        self.proj_2x = nn.Conv3d(16, inner_dim, kernel_size=(2, 4, 4), stride=(2, 4, 4))
+        self.proj_4x = nn.Conv3d(16, inner_dim, kernel_size=(4, 8, 8), stride=(4, 8, 8))
+
+
+class Transformer2DModelOutput(SimpleNamespace):
+    """`return_dict=True` result (the reference returns diffusers' dataclass with a `.sample` field)."""
+
+
+# --------------------------------------------------------------------------------------------
+# the model
+# --------------------------------------------------------------------------------------------
+class HunyuanVideoTransformer3DModelPacked(nn.Module):
+    """ref diffusers_helper/models/hunyuan_video_packed.py:698-774 (constructor and attributes)."""
+
+    def __init__(self, in_channels: int = 16, out_channels: int = 16, num_attention_heads: int = 24,
+                 attention_head_dim: int = 128, num_layers: int = 20, num_single_layers: int = 40,
+                 num_refiner_layers: int = 2, mlp_ratio: float = 4.0, patch_size: int = 2, patch_size_t: int = 1,
+                 qk_norm: str = "rms_norm", guidance_embeds: bool = True, text_embed_dim: int = 4096,
+                 pooled_projection_dim: int = 768, rope_theta: float = 256.0, rope_axes_dim=(16, 56, 56),
+                 has_image_proj=False, image_proj_dim=1152, has_clean_x_embedder=False) -> None:
+        super().__init__()
+        if attention_head_dim != 128:
+            raise ValueError("the gfx950 kernels are built for attention_head_dim == 128")
+        self.config = dict(in_channels=in_channels, out_channels=out_channels, num_attention_heads=num_attention_heads,
+                           attention_head_dim=attention_head_dim, num_layers=num_layers,
+                           num_single_layers=num_single_layers, num_refiner_layers=num_refiner_layers,
+                           mlp_ratio=mlp_ratio, patch_size=patch_size, patch_size_t=patch_size_t, qk_norm=qk_norm,
+                           guidance_embeds=guidance_embeds, text_embed_dim=text_embed_dim,
+                           pooled_projection_dim=pooled_projection_dim, rope_theta=rope_theta,
+                           rope_axes_dim=tuple(rope_axes_dim), has_image_proj=has_image_proj,
+                           image_proj_dim=image_proj_dim, has_clean_x_embedder=has_clean_x_embedder)
+        inner_dim = num_attention_heads * attention_head_dim
+        out_channels = out_channels or in_channels
+        self.heads, self.head_dim = num_attention_heads, attention_head_dim
+
+        self.x_embedder = HunyuanVideoPatchEmbed((patch_size_t, patch_size, patch_size), in_channels, inner_dim)
+        self.context_embedder = HunyuanVideoTokenRefiner(text_embed_dim, num_attention_heads, attention_head_dim,
+                                                         num_layers=num_refiner_layers)
+        self.time_text_embed = _TimeTextEmbed(inner_dim, pooled_projection_dim, guidance=True)
+        self.clean_x_embedder = None
+        self.image_projection = None
+        self.transformer_blocks = nn.ModuleList([
+            HunyuanVideoTransformerBlock(num_attention_heads, attention_head_dim, mlp_ratio, qk_norm)
+            for _ in range(num_layers)])
+        self.single_transformer_blocks = nn.ModuleList([
+            HunyuanVideoSingleTransformerBlock(num_attention_heads, attention_head_dim, mlp_ratio, qk_norm)
+            for _ in range(num_single_layers)])
+        self.norm_out = _AdaLinear(inner_dim, 2 * inner_dim)
+        self.proj_out = nn.Linear(inner_dim, patch_size_t * patch_size * patch_size * out_channels)
+
+        self.inner_dim = inner_dim
+        self.use_gradient_checkpointing = False
+        self.enable_teacache = False
+        if has_image_proj:
+            self.install_image_projection(image_proj_dim)
+        if has_clean_x_embedder:
+            self.install_clean_x_embedder()
+        self.high_quality_fp32_output_for_inference = False
+
+        self._rope_cache = RopeCache(rope_axes_dim, rope_theta)
+        self._packed = None            # fused weight buffers, built lazily (see _pack)
+        self._ws = {}                  # activation workspaces keyed by (S, device)
+        self.taps = None               # optional dict: per-block outputs for parity tests
+
+    # ---- reference API ---------------------------------------------------------------------
+    def install_image_projection(self, in_channels):
+        self.image_projection = ClipVisionProjection(in_channels=in_channels, out_channels=self.inner_dim)
+        self.config["has_image_proj"] = True
+        self.config["image_proj_dim"] = in_channels
+
+    def install_clean_x_embedder(self):
+        self.clean_x_embedder = HunyuanVideoPatchEmbedForCleanLatents(self.inner_dim)
+        self.config["has_clean_x_embedder"] = True
+
+    def initialize_teacache(self, enable_teacache=True, num_steps=25, rel_l1_thresh=0.15, _=None):
+        """ref :785-813."""
+        self.enable_teacache = enable_teacache
+        self.cnt = 0
+        self.num_steps = num_steps
+        self.rel_l1_thresh = rel_l1_thresh
+        self.accumulated_rel_l1_distance = 0
+        self.previous_modulated_input = None
+        self.previous_residual = None
+        self.teacache_rescale_func = np.poly1d(
+            [7.33226126e+02, -4.01131952e+02, 6.75869174e+01, -3.14987800e+00, 9.61237896e-02])
+        self.cache_hits = 0
+        self.cache_misses = 0
+        self.cache_queries = 0
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=None, **_):
+        """Local directory with config.json + *.safetensors (ref framepack/models.py:234-238 loads
+        lllyasviel/FramePackI2V_HY this way; hub names are not resolvable offline)."""
+        from safetensors.torch import load_file
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path}: from_pretrained needs a local model directory (no network)")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        model = cls(**cfg)
+        sd = {}
+        for name in sorted(os.listdir(path)):
+            if name.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, name)))
+        model.load_state_dict(sd, strict=True)
+        return model.to(torch_dtype) if torch_dtype is not None else model
+
+    # ---- weight fusion ---------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):                      # .to() / .cuda() / .half(): fused buffers go stale
+        self._packed = None
+        self._ws = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
+
+    @staticmethod
+    def _dense_weight(lin: nn.Linear) -> torch.Tensor:
+        """bf16 weight of a Linear; FP8 layers (E4M3 weight + `scale_weight` buffer, ref
+        utils/fp8_optimization_utils.py:216-226) are dequantised once here: numerically the reference's
+        W8A16 path (dequantise, then a bf16 GEMM), without repeating the dequantisation every call."""
+        w = lin.weight.detach()
+        sw = getattr(lin, "scale_weight", None)
+        if sw is not None:
+            return (w.to(sw.dtype) * sw).to(BF16)
+        return w.to(BF16)
+
+    def _fuse(self, linears):
+        ws = [self._dense_weight(l) for l in linears]
+        W = torch.cat(ws, dim=0).contiguous()
+        b = torch.cat([l.bias.detach().to(BF16) for l in linears], dim=0).contiguous()
+        # re-point plain bf16 parameters at slices of the fused buffer: no second copy stays alive
+        r0 = 0
+        for l, w in zip(linears, ws):
+            n = w.shape[0]
+            if l.weight.dtype == BF16 and getattr(l, "scale_weight", None) is None:
+                l.weight.data = W[r0:r0 + n]
+                l.bias.data = b[r0:r0 + n]
+            r0 += n
+        return W, b
+
+    def _pack(self):
+        P = SimpleNamespace(double=[], single=[])
+        mods = []
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            e = SimpleNamespace()
+            e.w_qkv, e.b_qkv = self._fuse([a.to_q, a.to_k, a.to_v])
+            e.w_qkv_c, e.b_qkv_c = self._fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj])
+            e.w_out, e.b_out = self._fuse([a.to_out[0]])
+            e.w_out_c, e.b_out_c = self._fuse([a.to_add_out])
+            e.w_ff1, e.b_ff1 = self._fuse([blk.ff.net[0].proj])
+            e.w_ff2, e.b_ff2 = self._fuse([blk.ff.net[2]])
+            e.w_ff1_c, e.b_ff1_c = self._fuse([blk.ff_context.net[0].proj])
+            e.w_ff2_c, e.b_ff2_c = self._fuse([blk.ff_context.net[2]])
+            e.nq, e.nk = a.norm_q.weight.detach().to(BF16).contiguous(), a.norm_k.weight.detach().to(BF16).contiguous()
+            e.nq_c = a.norm_added_q.weight.detach().to(BF16).contiguous()
+            e.nk_c = a.norm_added_k.weight.detach().to(BF16).contiguous()
+            P.double.append(e)
+            mods += [blk.norm1.linear, blk.norm1_context.linear]
+        for blk in self.single_transformer_blocks:
+            a = blk.attn
+            e = SimpleNamespace()
+            e.w_in, e.b_in = self._fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp])       # [k | v | q | mlp]
+            e.w_out, e.b_out = self._fuse([blk.proj_out])
+            e.nq, e.nk = a.norm_q.weight.detach().to(BF16).contiguous(), a.norm_k.weight.detach().to(BF16).contiguous()
+            P.single.append(e)
+            mods.append(blk.norm.linear)
+        mods.append(self.norm_out.linear)
+        # every AdaLN modulation of the forward depends only on temb: ONE weight-streaming GEMV per step
+        P.w_mod, P.b_mod = self._fuse(mods)
+        P.w_xe = self.x_embedder.proj.weight.detach().to(BF16).flatten(1).contiguous()
+        P.b_xe = self.x_embedder.proj.bias.detach().to(BF16).contiguous()
+        if self.clean_x_embedder is not None:
+            P.w_ce = [getattr(self.clean_x_embedder, n).weight.detach().to(BF16).flatten(1).contiguous()
+                      for n in ("proj", "proj_2x", "proj_4x")]
+            P.b_ce = [getattr(self.clean_x_embedder, n).bias.detach().to(BF16).contiguous()
+                      for n in ("proj", "proj_2x", "proj_4x")]
+        self._packed = P
+        return P
+
+    def _workspace(self, S: int, device):
+        key = (S, str(device))
+        ws = self._ws.get(key)
+        if ws is None:
+            d = self.inner_dim
+            m = self.transformer_blocks[0].ff.net[0].proj.out_features if len(self.transformer_blocks) else 4 * d
+            self._ws = {}                                     # one shape at a time (sections keep S fixed)
+            ws = SimpleNamespace(X=torch.empty((S, d), dtype=BF16, device=device),
+                                 N=torch.empty((S, d), dtype=BF16, device=device),
+                                 Y=torch.empty((S, 3 * d + m), dtype=BF16, device=device),
+                                 acc=torch.zeros((2,), dtype=torch.float32, device=device))
+            self._ws[key] = ws
+        return ws
+
+    # ---- packing of the input streams (ref :822-879) ----------------------------------------
+    def _embed_stream(self, x, kernel, w, b, out):
+        rows = patch_rows(pad_to_multiple(x, kernel), kernel)
+        ops.gemm(rows, w, b, out=out)
+
+    def process_input_hidden_states(self, latents, latent_indices=None, clean_latents=None, clean_latent_indices=None,
+                                    clean_latents_2x=None, clean_latent_2x_indices=None, clean_latents_4x=None,
+                                    clean_latent_4x_indices=None, out: Optional[torch.Tensor] = None):
+        """Returns (hidden [B,Si,d], rope [B,Si,256] fp32), token order [4x | 2x | 1x clean | noisy]."""
+        P = self._packed or self._pack()
+        B, C, T, H, W = latents.shape
+        assert B == 1
+        pt, p = self.config["patch_size_t"], self.config["patch_size"]
+        t, h, w = T // pt, H // p, W // p
+        if latent_indices is None:
+            latent_indices = torch.arange(0, t).unsqueeze(0).expand(B, -1)
+        streams = []     # (tensor, kernel, weight idx, indices, pool) in FINAL order
+        if clean_latents_4x is not None and clean_latent_4x_indices is not None:
+            streams.append((clean_latents_4x, (4, 8, 8), 2, clean_latent_4x_indices, 4))
+        if clean_latents_2x is not None and clean_latent_2x_indices is not None:
+            streams.append((clean_latents_2x, (2, 4, 4), 1, clean_latent_2x_indices, 2))
+        if clean_latents is not None and clean_latent_indices is not None:
+            streams.append((clean_latents, (1, 2, 2), 0, clean_latent_indices, 1))
+        streams.append((latents, (pt, p, p), -1, latent_indices, 1))
+
+        def ntok(x, k):
+            return -(-x.shape[2] // k[0]) * -(-x.shape[3] // k[1]) * -(-x.shape[4] // k[2])
+
+        counts = [ntok(x, k) for x, k, *_ in streams[:-1]] + [t * h * w]
+        Si = sum(counts)
+        if out is None:
+            out = torch.empty((Si, self.inner_dim), dtype=BF16, device=latents.device)
+        r0 = 0
+        for (x, k, wi, _, _), n in zip(streams, counts):
+            x = x.to(latents)                                           # ref :841, 852, 866
+            if wi < 0:                                                  # Conv3d floors a ragged edge (no padding)
+                x = x[:, :, :t * pt, :h * p, :w * p]
+                self._embed_stream(x, k, P.w_xe, P.b_xe, out[r0:r0 + n])
+            else:
+                self._embed_stream(x, k, P.w_ce[wi], P.b_ce[wi], out[r0:r0 + n])
+            r0 += n
+        rope = self._rope_cache.get([(i, pool) for _, _, _, i, pool in streams], h, w, latents.device)
+        return out[:Si].unsqueeze(0), rope
+
+    # ---- the blocks -------------------------------------------------------------------------
+    def _double_block(self, e, mod_i, mod_c, ws, Si, S, rope):
+        d, H = self.inner_dim, self.heads
+        X, N, Y = ws.X, ws.N, ws.Y
+        sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod_i.chunk(6)
+        csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = mod_c.chunk(6)
+        ops.layernorm_modulate(X[:Si], sc_a, sh_a, out=N[:Si])
+        ops.layernorm_modulate(X[Si:], csc_a, csh_a, out=N[Si:])
+        qkv = Y[:, :3 * d]
+        ops.gemm(N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
+        ops.gemm(N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
+        q, k, v = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
+        ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H, wq_txt=e.nq_c, wk_txt=e.nk_c)
+        ops.attention(q, k, v, H, out=q)
+        ops.gemm(q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
+        ops.gemm(q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
+        ops.layernorm_modulate(X[:Si], sc_m, sh_m, out=N[:Si])
+        ops.layernorm_modulate(X[Si:], csc_m, csh_m, out=N[Si:])
+        Fh = Y[:, 3 * d:]
+        ops.gemm(N[:Si], e.w_ff1, e.b_ff1, out=Fh[:Si], epilogue=ops.EPI_GELU)
+        ops.gemm(N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
+        ops.gemm(Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_m)
+        ops.gemm(Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_m)
+
+    def _single_block(self, e, mod, ws, Si, S, rope):
+        d, H = self.inner_dim, self.heads
+        X, N, Y = ws.X, ws.N, ws.Y
+        shift, scale, gate = mod.chunk(3)
+        ops.layernorm_modulate(X, scale, shift, out=N)
+        ops.gemm(N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)   # [k | v | q | gelu(mlp)]
+        k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
+        ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H)
+        ops.attention(q, k, v, H, out=q)
+        ops.gemm(Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
+
+    def _run_blocks(self, P, mods, ws, Si, S, rope):
+        d = self.inner_dim
+        o = 0
+        for i, e in enumerate(P.double):
+            self._double_block(e, mods[o:o + 6 * d], mods[o + 6 * d:o + 12 * d], ws, Si, S, rope)
+            o += 12 * d
+            if self.taps is not None:
+                self.taps[f"double.{i}"] = (ws.X[:Si].clone(), ws.X[Si:].clone())
+        for i, e in enumerate(P.single):
+            self._single_block(e, mods[o:o + 3 * d], ws, Si, S, rope)
+            o += 3 * d
+            if self.taps is not None:
+                self.taps[f"single.{i}"] = (ws.X[:Si].clone(), ws.X[Si:].clone())
+
+    # ---- forward ----------------------------------------------------------------------------
+    def forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, pooled_projections,
+                guidance, latent_indices=None, clean_latents=None, clean_latent_indices=None, clean_latents_2x=None,
+                clean_latent_2x_indices=None, clean_latents_4x=None, clean_latent_4x_indices=None,
+                image_embeddings=None, attention_kwargs=None, return_dict=True):
+        """ref :881-1062.  Same arguments, same result tuple / `.sample`, same exceptions."""
+        shape = hidden_states.shape
+        if len(shape) == 4:
+            batch_size, num_frames, height, width = shape
+        elif len(shape) == 5:
+            batch_size, channels, num_frames, height, width = shape
+        else:
+            raise ValueError(f"Unexpected hidden_states shape: {shape}. Expected 4D (B,F,H,W) or 5D (B,C,F,H,W) tensor.")
+        if not hidden_states.is_cuda:
+            raise RuntimeError("HunyuanVideoTransformer3DModelPacked (MI355X build) runs on the GPU only; "
+                               "there is no CPU fallback")
+        if hidden_states.dtype != BF16 or self.dtype != BF16:
+            raise TypeError("the gfx950 kernels compute in bf16: load the model and pass hidden_states as torch.bfloat16")
+        _lib.load()
+        with torch.no_grad():
+            return self._forward(hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
+                                 pooled_projections, guidance, latent_indices, clean_latents, clean_latent_indices,
+                                 clean_latents_2x, clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices,
+                                 image_embeddings, return_dict)
+
+    def _forward(self, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, pooled_projections,
+                 guidance, latent_indices, clean_latents, clean_latent_indices, clean_latents_2x,
+                 clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices, image_embeddings, return_dict):
+        dev = hidden_states.device
+        B, C, T, Hh, Ww = hidden_states.shape
+        p, p_t = self.config["patch_size"], self.config["patch_size_t"]
+        t2, h2, w2 = T // p_t, Hh // p, Ww // p
+        ctx_len = t2 * h2 * w2
+        d = self.inner_dim
+        P = self._packed or self._pack()
+
+        # conditioning (tiny, once per step): temb, refined text context, image projection
+        temb = self.time_text_embed.timestep_embedder(_sinusoid_256(timestep).to(pooled_projections.dtype)) \
+            + self.time_text_embed.guidance_embedder(_sinusoid_256(guidance).to(pooled_projections.dtype)) \
+            + self.time_text_embed.text_embedder(pooled_projections)
+        encoder_attention_mask = encoder_attention_mask.to(dev)
+        ctx = self.context_embedder(encoder_hidden_states, timestep, encoder_attention_mask)
+        mask = encoder_attention_mask
+        if self.image_projection is not None:
+            assert image_embeddings is not None, "You must use image embeddings!"
+            extra = self.image_projection(image_embeddings)
+            ctx = torch.cat([extra, ctx], dim=1)                     # image tokens before text (ref :922-923)
+            mask = torch.cat([torch.ones((B, extra.shape[1]), dtype=mask.dtype, device=mask.device), mask], dim=1)
+
+        if B != 1:
+            # Parity target = the reference's SDPA-only configuration, which has no varlen path for B > 1
+            # (ref :106-109).  The K1 kernel takes cu_seqlens (packing.get_cu_seqlens), the host loop does not yet.
+            raise NotImplementedError("No Attn Installed!")
+        text_len = int(mask.sum().item())                           # ref :930 (one host sync per step)
+        ctx = ctx[:, :text_len]
+
+        # packed image tokens straight into the residual-stream buffer
+        n_img = self._count_image_tokens(hidden_states, clean_latents, clean_latent_indices, clean_latents_2x,
+                                         clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices)
+        S = n_img + text_len
+        ws = self._workspace(S, dev)
+        _, rope = self.process_input_hidden_states(hidden_states, latent_indices, clean_latents, clean_latent_indices,
+                                                   clean_latents_2x, clean_latent_2x_indices, clean_latents_4x,
+                                                   clean_latent_4x_indices, out=ws.X[:n_img])
+        ws.X[n_img:].copy_(ctx[0])
+        rope = rope[0]
+        Si = n_img
+
+        # all AdaLN modulations of this step: one GEMV over the concatenated modulation weights
+        mods = ops.silu_gemv(temb[0], P.w_mod, P.b_mod)
+
+        if self.taps is not None:
+            self.taps["packed_hidden"], self.taps["rope"] = ws.X[:Si].clone(), rope
+            self.taps["temb"], self.taps["text_ctx"] = temb, ctx
+
+        if self.enable_teacache:
+            sh_a, sc_a = mods[:d], mods[d:2 * d]
+            modulated = ops.layernorm_modulate(ws.X[:Si], sc_a, sh_a)                       # ref :945
+            self.cache_queries += 1
+            curr = 0.0
+            if self.cnt == 0 or self.cnt == self.num_steps - 1:
+                should_calc = True
+                self.accumulated_rel_l1_distance = 0
+                self.cache_misses += 1
+            else:
+                acc = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc).tolist()   # host sync (ref :958)
+                n = modulated.numel()
+                curr = (acc[0] / n) / (acc[1] / n + 1e-8)
+                self.accumulated_rel_l1_distance += self.teacache_rescale_func(curr)
+                should_calc = self.accumulated_rel_l1_distance >= self.rel_l1_thresh
+                if should_calc:
+                    self.accumulated_rel_l1_distance = 0
+                    self.cache_misses += 1
+                else:
+                    self.cache_hits += 1
+            self.previous_modulated_input = modulated
+            self.cnt += 1
+            if self.cnt == self.num_steps:
+                self.cnt = 0
+            self.cache_info = {"hits": self.cache_hits, "misses": self.cache_misses, "queries": self.cache_queries,
+                               "hit_rate": self.cache_hits / max(1, self.cache_queries), "step": self.cnt,
+                               "curr_rel_l1": curr, "accumulated_distance": self.accumulated_rel_l1_distance}
+            if not should_calc:
+                ws.X[:Si].add_(self.previous_residual)
+            else:
+                ori = ws.X[:Si].clone()
+                self._run_blocks(P, mods, ws, Si, S, rope)
+                self.previous_residual = ws.X[:Si] - ori
+        else:
+            self._run_blocks(P, mods, ws, Si, S, rope)
+
+        # output head (ref :1044-1057): norm_out is token-wise, so slice first; (scale, shift) order of :501
+        scale, shift = mods[-2 * d:-d], mods[-d:]
+        head_in = ops.layernorm_modulate(ws.X[Si - ctx_len:Si], scale, shift, out=ws.N[:ctx_len])
+        if self.high_quality_fp32_output_for_inference:
+            if self.proj_out.weight.dtype != torch.float32:
+                self.proj_out.to(dtype=torch.float32)
+                self._packed = P          # proj_out is not part of the fused buffers
+            out = F.linear(head_in.float(), self.proj_out.weight, self.proj_out.bias)
+        else:
+            out = ops.gemm(head_in, self.proj_out.weight.detach(), self.proj_out.bias.detach())
+        if self.taps is not None:
+            self.taps["head"] = out
+        out = unpatchify(out, B, t2, h2, w2, self.config["out_channels"], p_t, p)
+        if return_dict:
+            return Transformer2DModelOutput(sample=out)
+        return (out,)
+
+    def _count_image_tokens(self, latents, c1, i1, c2, i2, c4, i4) -> int:
+        p, p_t = self.config["patch_size"], self.config["patch_size_t"]
+        _, _, T, H, W = latents.shape
+        n = (T // p_t) * (H // p) * (W // p)
+
+        def cnt(x, k):
+            return -(-x.shape[2] // k[0]) * -(-x.shape[3] // k[1]) * -(-x.shape[4] // k[2])
+        if c1 is not None and i1 is not None:
+            n += cnt(c1, (1, 2, 2))
+        if c2 is not None and i2 is not None:
+            n += cnt(c2, (2, 4, 4))
+        if c4 is not None and i4 is not None:
+            n += cnt(c4, (4, 8, 8))
+        return n

@@ -14,6 +14,10 @@ from . import lib as _lib
 
 BF16 = torch.bfloat16
 
+# bench.py sets this to a list to time the dominant kernel live: every attention launch is then bracketed by
+# two events recorded on the stream it is launched on (appended as (start, end, tokens, heads)).
+ATTN_EVENTS: Optional[list] = None
+
 
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
@@ -113,9 +117,16 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
         max_seqlen = rows
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
+    ev = None
+    if ATTN_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(q.device))
     _lib.check(_lib.load().fp_attn_fwd_bf16(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o2.data_ptr(), qs, ks, vs, os_,
                                             _ptr(cu_seqlens), nseg, max_seqlen, rows, heads, 128, scale, _stream(q)),
                "fp_attn_fwd_bf16")
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(q.device))
+        ATTN_EVENTS.append((ev[0], ev[1], rows, heads))
     return out
 
 

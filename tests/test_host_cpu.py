@@ -1,0 +1,121 @@
+"""CPU-side checks of the host mirror: state-dict names/shapes, bit-exact packing tables, the C-ABI library
+exporting every declared symbol, loud failure without a GPU.  No GPU compute happens here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from framepack_amd import lib, packing, synthetic
+from framepack_amd.model import HunyuanVideoTransformer3DModelPacked
+from oracle import dit_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    m = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_TINY)
+    synthetic.init_synthetic_(dict(m.state_dict()), seed=0)
+    return m
+
+
+def test_state_dict_names_and_shapes_match_reference_layout(tiny_model):
+    shapes = O.param_shapes(O.DiTConfig(**synthetic.CONFIG_TINY))
+    sd = tiny_model.state_dict()
+    assert set(sd) == set(shapes)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+
+
+def test_13b_layout_has_the_documented_dimensions():
+    shapes = O.param_shapes(O.DiTConfig(**synthetic.CONFIG_13B))
+    # ref utils/lora_utils.py:195-206: hidden 3072, fused single-block width 21504 = 3*3072 + 12288
+    assert shapes["single_transformer_blocks.39.proj_out.weight"] == (3072, 15360)
+    assert shapes["transformer_blocks.19.norm1.linear.weight"] == (18432, 3072)
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert 12.5e9 < n < 13.5e9
+
+
+def test_synthetic_init_equals_oracle_params(tiny_model):
+    P = O.synth_params(O.DiTConfig(**synthetic.CONFIG_TINY), seed=0)
+    sd = tiny_model.state_dict()
+    for k in P:
+        assert torch.equal(sd[k], P[k]), k
+
+
+def test_fp8_targets_are_linear_modules(tiny_model):
+    """ref utils/fp8_optimization_utils.py:258-272 patches nn.Linear instances found by these names."""
+    mods = dict(tiny_model.named_modules())
+    for k in tiny_model.state_dict():
+        if ("transformer_blocks" in k) and k.endswith(".weight") and "norm" not in k:
+            assert isinstance(mods[k[:-len(".weight")]], torch.nn.Linear), k
+
+
+@pytest.mark.parametrize("name,pool", [("noisy", 1), ("clean", 1), ("x2", 2), ("x4", 4), ("x2_odd", 2), ("x4_odd", 4),
+                                       ("x4_pad", 4)])
+def test_rope_tables_bit_exact(golden_dir, name, pool):
+    G = np.load(os.path.join(golden_dir, "rope.npz"))
+    h, w = (int(v) for v in G[name + "_hw"])
+    t = packing.rope_tokens(torch.from_numpy(G[name + "_idx"]), h, w, pool)
+    assert np.array_equal(t.numpy(), G[name])
+
+
+def test_rope_cache_concatenates_streams_in_packed_order(golden_dir):
+    G = np.load(os.path.join(golden_dir, "rope.npz"))
+    c = packing.RopeCache((16, 56, 56), 256.0)
+    streams = [(torch.from_numpy(G["x4_idx"]), 4), (torch.from_numpy(G["x2_idx"]), 2),
+               (torch.from_numpy(G["clean_idx"]), 1), (torch.from_numpy(G["noisy_idx"]), 1)]
+    t = c.get(streams, 6, 8, "cpu")
+    want = np.concatenate([G["x4"], G["x2"], G["clean"], G["noisy"]], axis=1)
+    assert np.array_equal(t.numpy(), want)
+    assert c.get(streams, 6, 8, "cpu") is t                       # cached
+
+
+def test_replicate_pad_and_patch_rows_match_conv3d(golden_dir):
+    G = np.load(os.path.join(golden_dir, "rope.npz"))
+    r = torch.arange(2 * 3 * 5 * 7, dtype=torch.float32).view(1, 2, 3, 5, 7)
+    assert np.array_equal(packing.pad_to_multiple(r, (2, 4, 8)).numpy(), G["pad_248"])
+    g = torch.Generator("cpu").manual_seed(0)
+    x = torch.randn(1, 16, 4, 8, 16, generator=g)
+    w = torch.randn(32, 16, 2, 4, 4, generator=g)
+    want = torch.nn.functional.conv3d(x, w, stride=(2, 4, 4)).flatten(2).transpose(1, 2)[0]
+    got = packing.patch_rows(x, (2, 4, 4)) @ w.flatten(1).T
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4)
+
+
+def test_unpatchify_matches_einops_pattern():
+    import einops
+    x = torch.arange(1 * 24 * 64, dtype=torch.float32).view(1, 24, 64)
+    want = einops.rearrange(x, "b (t h w) (c pt ph pw) -> b c (t pt) (h ph) (w pw)", t=2, h=3, w=4, pt=1, ph=2, pw=2)
+    assert torch.equal(packing.unpatchify(x[0], 1, 2, 3, 4, 16, 1, 2), want)
+
+
+def test_cu_seqlens_layout():
+    mask = torch.zeros(2, 8, dtype=torch.bool)
+    mask[0, :3] = True
+    mask[1, :] = True
+    assert packing.get_cu_seqlens(mask, 10).tolist() == O.get_cu_seqlens(mask, 10).tolist() == [0, 13, 18, 36, 36]
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "framepack_hip.h")).read()
+    declared = set(re.findall(r"^int\s+(fp_\w+)\s*\(", header, flags=re.M))
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    so = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(so, name), name
+    assert lib.load().fp_abi_version() == 1
+
+
+def test_forward_refuses_cpu_tensors(tiny_model):
+    kw = synthetic.make_inputs(frames_latent=1, height=64, width=64, n_text=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tiny_model.to(torch.bfloat16)(return_dict=False, **kw)
+
+
+def test_bad_rank_raises_value_error(tiny_model):
+    with pytest.raises(ValueError, match="Unexpected hidden_states shape"):
+        tiny_model(torch.zeros(2, 2, 2), None, None, None, None, None)
