@@ -279,6 +279,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._packed = None            # fused weight buffers, built lazily (see _pack)
         self._ws = {}                  # activation workspaces keyed by (S, device)
         self.taps = None               # optional dict: per-block outputs for parity tests
+        self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
 
     # ---- reference API ---------------------------------------------------------------------
     def install_image_projection(self, in_channels):
@@ -304,6 +305,27 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.cache_hits = 0
         self.cache_misses = 0
         self.cache_queries = 0
+
+    def enable_sequence_parallel(self, group=None):
+        """Shard the image tokens over the ranks of `group` (default: the world) and run the joint attention
+        Ulysses-style (framepack_amd/ulysses.py).  Every rank calls forward() with the SAME inputs and gets
+        the SAME full output; weights are replicated.  No reference counterpart."""
+        import torch.distributed as dist
+        self.sp_group = group
+        self.sp_world = dist.get_world_size(group)
+        self.sp_rank = dist.get_rank(group)
+        if self.heads % self.sp_world != 0:
+            raise ValueError(f"{self.heads} heads do not divide over {self.sp_world} ranks")
+        self._ws = {}
+
+    def _attend(self, q, k, v, n_img):
+        """Joint attention over [image rows | text rows]; output written over q."""
+        if self.sp_world == 1:
+            ops.attention(q, k, v, self.heads, out=q)
+        else:
+            from .ulysses import ulysses_attention
+            ulysses_attention(q, k, v, n_img, self.heads, self.head_dim,
+                              lambda jq, jk, jv, h, o: ops.attention(jq, jk, jv, h, out=o), self.sp_group, out=q)
 
     @property
     def device(self):
@@ -366,6 +388,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         return W, b
 
     def _pack(self):
+        # callers run under torch.inference_mode() (ref k_diffusion_hunyuan.py:27): the fused buffers must be
+        # ordinary tensors, because parameters are re-pointed at them
+        with torch.inference_mode(False), torch.no_grad():
+            return self._pack_impl()
+
+    def _pack_impl(self):
         P = SimpleNamespace(double=[], single=[])
         mods = []
         for blk in self.transformer_blocks:
@@ -476,7 +504,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         ops.gemm(N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
         q, k, v = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
         ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H, wq_txt=e.nq_c, wk_txt=e.nk_c)
-        ops.attention(q, k, v, H, out=q)
+        self._attend(q, k, v, Si)
         ops.gemm(q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
         ops.gemm(q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
         ops.layernorm_modulate(X[:Si], sc_m, sh_m, out=N[:Si])
@@ -495,7 +523,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         ops.gemm(N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)   # [k | v | q | gelu(mlp)]
         k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
         ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H)
-        ops.attention(q, k, v, H, out=q)
+        self._attend(q, k, v, Si)
         ops.gemm(Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
 
     def _run_blocks(self, P, mods, ws, Si, S, rope):
@@ -571,14 +599,28 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         # packed image tokens straight into the residual-stream buffer
         n_img = self._count_image_tokens(hidden_states, clean_latents, clean_latent_indices, clean_latents_2x,
                                          clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices)
-        S = n_img + text_len
-        ws = self._workspace(S, dev)
-        _, rope = self.process_input_hidden_states(hidden_states, latent_indices, clean_latents, clean_latent_indices,
-                                                   clean_latents_2x, clean_latent_2x_indices, clean_latents_4x,
-                                                   clean_latent_4x_indices, out=ws.X[:n_img])
-        ws.X[n_img:].copy_(ctx[0])
-        rope = rope[0]
-        Si = n_img
+        if self.sp_world == 1:
+            lo, Si = 0, n_img
+            S = Si + text_len
+            ws = self._workspace(S, dev)
+            _, rope = self.process_input_hidden_states(hidden_states, latent_indices, clean_latents,
+                                                       clean_latent_indices, clean_latents_2x, clean_latent_2x_indices,
+                                                       clean_latents_4x, clean_latent_4x_indices, out=ws.X[:n_img])
+            rope = rope[0]
+        else:
+            # sequence parallel: this rank keeps image rows [lo, hi) (+ all text rows, replicated)
+            from .ulysses import shard_bounds
+            lo, hi = shard_bounds(n_img, self.sp_world, self.sp_rank)
+            Si = hi - lo
+            S = Si + text_len
+            ws = self._workspace(S, dev)
+            full, rope = self.process_input_hidden_states(hidden_states, latent_indices, clean_latents,
+                                                          clean_latent_indices, clean_latents_2x,
+                                                          clean_latent_2x_indices, clean_latents_4x,
+                                                          clean_latent_4x_indices)
+            ws.X[:Si].copy_(full[0, lo:hi])
+            rope = rope[0, lo:hi].contiguous()
+        ws.X[Si:].copy_(ctx[0])
 
         # all AdaLN modulations of this step: one GEMV over the concatenated modulation weights
         mods = ops.silu_gemv(temb[0], P.w_mod, P.b_mod)
@@ -597,8 +639,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                 self.accumulated_rel_l1_distance = 0
                 self.cache_misses += 1
             else:
-                acc = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc).tolist()   # host sync (ref :958)
-                n = modulated.numel()
+                acc_t = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc)
+                if self.sp_world > 1:                       # identical decision on every rank
+                    import torch.distributed as dist
+                    dist.all_reduce(acc_t, group=self.sp_group)
+                acc = acc_t.tolist()                                           # host sync (ref :958)
+                n = modulated.numel() * self.sp_world
                 curr = (acc[0] / n) / (acc[1] / n + 1e-8)
                 self.accumulated_rel_l1_distance += self.teacache_rescale_func(curr)
                 should_calc = self.accumulated_rel_l1_distance >= self.rel_l1_thresh
@@ -625,7 +671,10 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
 
         # output head (ref :1044-1057): norm_out is token-wise, so slice first; (scale, shift) order of :501
         scale, shift = mods[-2 * d:-d], mods[-d:]
-        head_in = ops.layernorm_modulate(ws.X[Si - ctx_len:Si], scale, shift, out=ws.N[:ctx_len])
+        # rows of this rank that belong to the noisy-latent tokens (the last ctx_len rows of the image sequence)
+        first = max(0, (n_img - ctx_len) - lo)
+        head_in = ops.layernorm_modulate(ws.X[first:Si], scale, shift, out=ws.N[:Si - first]) if Si > first else \
+            ws.N[:0]
         if self.high_quality_fp32_output_for_inference:
             if self.proj_out.weight.dtype != torch.float32:
                 self.proj_out.to(dtype=torch.float32)
@@ -633,6 +682,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             out = F.linear(head_in.float(), self.proj_out.weight, self.proj_out.bias)
         else:
             out = ops.gemm(head_in, self.proj_out.weight.detach(), self.proj_out.bias.detach())
+        if self.sp_world > 1:
+            from .ulysses import gather_rows
+            n_loc = n_img // self.sp_world
+            padded = out.new_zeros((n_loc, out.shape[1]))
+            padded[n_loc - out.shape[0]:] = out
+            out = gather_rows(padded, self.sp_group)[n_img - ctx_len:]
         if self.taps is not None:
             self.taps["head"] = out
         out = unpatchify(out, B, t2, h2, w2, self.config["out_channels"], p_t, p)

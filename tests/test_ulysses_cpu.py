@@ -1,0 +1,69 @@
+"""Sequence-parallel exchange (framepack_amd.ulysses) on world_size-2 and -4 gloo groups on the CPU:
+sharded attention == unsharded attention.  The attention itself is injected (the oracle's SDPA here; the
+product injects the HIP kernel), so this covers the all-to-all index math, the replicated-text handling
+and the row gathers by construction."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from framepack_amd import ulysses
+from oracle import dit_oracle as O
+
+
+def _attn(q, k, v, heads, out):
+    S = q.shape[0]
+    o = O.sdpa_nhd(q.reshape(1, S, heads, 128), k.reshape(1, S, heads, 128), v.reshape(1, S, heads, 128))
+    out.copy_(o.reshape(S, heads * 128))
+    return out
+
+
+def _worker(rank, world, port, n_img_total, n_txt, heads, strided, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = heads * 128
+        g = torch.Generator("cpu").manual_seed(0)
+        q, k, v = (torch.randn(n_img_total + n_txt, d, generator=g) for _ in range(3))
+        full = torch.empty_like(q)
+        _attn(q, k, v, heads, full)
+        lo, hi = ulysses.shard_bounds(n_img_total, world, rank)
+        rows = torch.cat([torch.arange(lo, hi), torch.arange(n_img_total, n_img_total + n_txt)])
+        if strided:                                   # q|k|v as column ranges of one buffer, output over q
+            buf = torch.cat([q[rows], k[rows], v[rows], torch.zeros(len(rows), 64)], dim=1)
+            lq, lk, lv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
+            got = ulysses.ulysses_attention(lq, lk, lv, hi - lo, heads, 128, _attn, out=lq)
+        else:
+            got = ulysses.ulysses_attention(q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(),
+                                            hi - lo, heads, 128, _attn)
+        err = (got - full[rows]).abs().max().item()
+        gathered = ulysses.gather_rows(got[:hi - lo].contiguous())
+        err2 = (gathered - full[:n_img_total]).abs().max().item()
+        ret[rank] = max(err, err2)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n_img,n_txt,heads,strided", [(2, 64, 9, 2, False), (2, 50, 0, 4, True),
+                                                           (4, 40, 7, 4, True)])
+def test_ulysses_attention_equals_unsharded(world, n_img, n_txt, heads, strided):
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_img, n_txt, heads, strided, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    assert max(ret.values()) < 1e-5
+
+
+def test_shard_bounds_rejects_ragged_split():
+    with pytest.raises(ValueError):
+        ulysses.shard_bounds(10, 4, 0)
+    assert ulysses.shard_bounds(18400, 8, 7) == (16100, 18400)
