@@ -18,10 +18,10 @@
 //   * Tails: rows are clamped on load, scores of keys past the segment end are masked to -inf in the
 //     last tile only, query rows past the end are not stored.  Nothing is padded in memory.
 #include "fp_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int QBLK = 256;     // query rows per workgroup
 constexpr int KVBLK = 64;     // keys per tile
 constexpr int HD = 128;       // head dim
 constexpr int KBUF = KVBLK * HD * 2;   // 16 KiB per K (or V) buffer
@@ -33,8 +33,10 @@ __device__ __forceinline__ unsigned v_lds_off(int key, int chunk) {
     return (unsigned)((chunk >> 2) * (KVBLK * 64) + key * 64 + ((chunk & 3) << 4));
 }
 
-template <int THR_LOG2>      // defer-max threshold in log2 units (0 = rescale whenever the max grows)
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+// NW = waves per workgroup (32 query rows each); THR_LOG2 = defer-max threshold in log2 units
+// (0 = rescale whenever the max grows)
+template <int NW, int THR_LOG2>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
                                                           int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
                                                           const int* __restrict__ cu_seqlens, int nseg, int total,
@@ -43,6 +45,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     unsigned char* kbuf = smem;                 // [2][KBUF]
     unsigned char* vbuf = smem + 2 * KBUF;      // [2][KBUF]
 
+    constexpr int QBLK = 32 * NW, NT = 64 * NW, CPT = 1024 / NT;   // chunks per thread per operand tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
 
@@ -70,24 +73,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
         for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
     }
 
-    // ---- staging: 1024 16-B chunks per tile per operand, two per thread
-    const int sk0 = tid >> 4, sc = tid & 15;    // chunk ids tid and tid + 512: keys sk0 and sk0 + 32
+    // ---- staging: 1024 16-B chunks per tile per operand, CPT per thread
+    const int sk0 = tid >> 4, sc = tid & 15;    // chunk ids tid + NT*i: keys sk0 + (NT/16)*i
     const bf16* kbase = K + head * HD + sc * 8;
     const bf16* vbase = V + head * HD + sc * 8;
-    u32x4 kreg[2], vreg[2];
+    u32x4 kreg[CPT], vreg[CPT];
     auto stage_load = [&](int t) {
         const int kv0 = seg_lo + t * KVBLK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = min(kv0 + sk0 + 32 * i, seg_hi - 1);
+        for (int i = 0; i < CPT; ++i) {
+            const int row = min(kv0 + sk0 + (NT / 16) * i, seg_hi - 1);
             kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (int64_t)row * k_rs);
             vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (int64_t)row * v_rs);
         }
     };
     auto stage_write = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = sk0 + 32 * i;
+        for (int i = 0; i < CPT; ++i) {
+            const int key = sk0 + (NT / 16) * i;
             *reinterpret_cast<u32x4*>(kbuf + buf * KBUF + k_lds_off(key, sc)) = kreg[i];
             *reinterpret_cast<u32x4*>(vbuf + buf * KBUF + v_lds_off(key, sc)) = vreg[i];
         }
@@ -234,20 +237,27 @@ extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
                ((uintptr_t)o & 7) == 0);
     FP_REQUIRE(cu_seqlens || nseg == 1);
     if (total_tokens == 0 || max_seqlen == 0) return 0;
-    const int nqb = (max_seqlen + QBLK - 1) / QBLK;
-    const int64_t nwg = (int64_t)nqb * heads * nseg;
-    FP_REQUIRE(nwg < (1ll << 31));
-    constexpr int smem = 4 * KBUF;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
     const float scale_log2e = softmax_scale * 1.4426950408889634f;
-    attn_fwd_kernel<0><<<dim3((unsigned)nwg), dim3(512), smem, (hipStream_t)stream>>>(
-        (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
-        o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e);
+    int variant = 0;
+    if (const char* e = getenv("FP_ATTN_VARIANT")) variant = atoi(e);
+#define FP_LAUNCH_ATTN(NW_, THR_)                                                                                  \
+    do {                                                                                                           \
+        const int nqb = (max_seqlen + 32 * NW_ - 1) / (32 * NW_);                                                  \
+        const int64_t nwg = (int64_t)nqb * heads * nseg;                                                           \
+        FP_REQUIRE(nwg < (1ll << 31));                                                                             \
+        hipError_t e_ = hipFuncSetAttribute((const void*)attn_fwd_kernel<NW_, THR_>,                               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KBUF);                 \
+        if (e_ != hipSuccess) return (int)e_;                                                                      \
+        attn_fwd_kernel<NW_, THR_><<<dim3((unsigned)nwg), dim3(64 * NW_), 4 * KBUF, (hipStream_t)stream>>>(        \
+            (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,    \
+            o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e);                                \
+    } while (0)
+    switch (variant) {
+        case 1: FP_LAUNCH_ATTN(4, 0); break;
+        case 2: FP_LAUNCH_ATTN(8, 8); break;
+        case 3: FP_LAUNCH_ATTN(4, 8); break;
+        default: FP_LAUNCH_ATTN(8, 0); break;
+    }
     FP_CHECK_LAUNCH();
     return 0;
 }

@@ -1,0 +1,39 @@
+"""Micro-benchmark of the K1 attention kernel at the config-2 shape (S = 19385, 24 heads), random data.
+usage: python tools/bench_attn.py [S] [heads] [iters]   (env FP_ATTN_VARIANT selects an experimental variant)"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from framepack_amd import ops  # noqa: E402
+
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 19385
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+dev = "cuda:0"
+g = torch.Generator(device=dev).manual_seed(0)
+buf = torch.randn(S, 7 * H * 128, generator=g, device=dev).to(torch.bfloat16)   # single-block layout [k|v|q|mlp]
+d = H * 128
+k, v, q = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
+out = torch.empty(S, d, dtype=torch.bfloat16, device=dev)
+for variant in os.environ.get("VARIANTS", "0").split(","):
+    os.environ["FP_ATTN_VARIANT"] = variant
+    for _ in range(3):
+        ops.attention(q, k, v, H, out=out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        ops.attention(q, k, v, H, out=out)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / iters
+    fl = 4.0 * S * S * H * 128
+    # sampled-row check against fp64
+    rows = torch.tensor([0, 255, 256, S // 2, S - 1], device=dev)
+    qh, kh, vh = q[rows][:, :128].double(), k[:, :128].double(), v[:, :128].double()
+    ref = torch.softmax(qh @ kh.T / math.sqrt(128.0), -1) @ vh
+    err = ((out[rows][:, :128].double() - ref).norm() / ref.norm()).item()
+    print(f"variant {variant}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s  ({fl / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)  err {err:.2e}", flush=True)
