@@ -14,9 +14,12 @@ H = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
-buf = torch.randn(S, 7 * H * 128, generator=g, device=dev).to(torch.bfloat16)   # single-block layout [k|v|q|mlp]
 d = H * 128
-k, v, q = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
+if os.environ.get("LAYOUT", "fused") == "fused":
+    buf = torch.randn(S, 7 * d, generator=g, device=dev).to(torch.bfloat16)   # single-block layout [k|v|q|mlp]
+    k, v, q = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
+else:
+    k, v, q = (torch.randn(S, d, generator=g, device=dev).to(torch.bfloat16) for _ in range(3))
 out = torch.empty(S, d, dtype=torch.bfloat16, device=dev)
 for variant in os.environ.get("VARIANTS", "0").split(","):
     os.environ["FP_ATTN_VARIANT"] = variant
