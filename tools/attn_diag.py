@@ -1,3 +1,5 @@
+"""Per-segment cycle shares of the attention tile loop (stamped diagnostic build).
+Build first:  make -C framepack_amd/csrc clean && make -C framepack_amd/csrc DIAG=1 ; rebuild without DIAG afterwards."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from framepack_amd import ops, lib
@@ -6,11 +8,10 @@ d = H * 128
 g = torch.Generator(device="cuda:0").manual_seed(0)
 q, k, v = (torch.randn(S, d, generator=g, device="cuda:0").to(torch.bfloat16) for _ in range(3))
 out = torch.empty_like(q)
-os.environ["FP_ATTN_VARIANT"] = sys.argv[1] if len(sys.argv) > 1 else "7"
 for _ in range(3):
     ops.attention(q, k, v, H, out=out)
 torch.cuda.synchronize()
-L = ctypes.CDLL(os.path.join(os.path.dirname(lib.__file__), "libframepack_hip.so"))
+L = lib.load()
 buf = (ctypes.c_ulonglong * 64)()
 print("rc", L.fp_attn_dbg_read(buf))
 for w in range(8):

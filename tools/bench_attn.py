@@ -1,5 +1,5 @@
 """Micro-benchmark of the K1 attention kernel at the config-2 shape (S = 19385, 24 heads), random data.
-usage: python tools/bench_attn.py [S] [heads] [iters]   (env FP_ATTN_VARIANT selects an experimental variant)"""
+usage: python tools/bench_attn.py [S] [heads] [iters]"""
 import math
 import os
 import sys
@@ -21,8 +21,7 @@ if os.environ.get("LAYOUT", "fused") == "fused":
 else:
     k, v, q = (torch.randn(S, d, generator=g, device=dev).to(torch.bfloat16) for _ in range(3))
 out = torch.empty(S, d, dtype=torch.bfloat16, device=dev)
-for variant in os.environ.get("VARIANTS", "0").split(","):
-    os.environ["FP_ATTN_VARIANT"] = variant
+for variant in range(int(os.environ.get("REPEAT", "2"))):
     for _ in range(3):
         ops.attention(q, k, v, H, out=out)
     torch.cuda.synchronize()
@@ -39,4 +38,4 @@ for variant in os.environ.get("VARIANTS", "0").split(","):
     qh, kh, vh = q[rows][:, :128].double(), k[:, :128].double(), v[:, :128].double()
     ref = torch.softmax(qh @ kh.T / math.sqrt(128.0), -1) @ vh
     err = ((out[rows][:, :128].double() - ref).norm() / ref.norm()).item()
-    print(f"variant {variant}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s  ({fl / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)  err {err:.2e}", flush=True)
+    print(f"run {variant}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s  ({fl / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)  err {err:.2e}", flush=True)
