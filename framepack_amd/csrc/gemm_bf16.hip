@@ -1,279 +1,23 @@
-// K5: C = epilogue(A . W^T + bias), bf16 in / fp32 accumulate / bf16 out  (gfx950 MFMA 16x16x32, wave64)
-//
-// The nn.Linear of every DiT block (ref hunyuan_video_packed.py:119-121, 133-135, 154-156, 167-169, 552,
-// 570 and the diffusers FeedForward it calls at :646-647), with the elementwise work that follows each of
-// them in the reference fused into the epilogue: bias, tanh-GELU (optionally only on a column range: the
-// fused [k|v|q|mlp] projection of the single-stream blocks) and the gated residual `R + gate * (.)`.
-//
-// Both operands are K-contiguous ("NT"): A [M,K] tokens x features, W [N,K] nn.Linear layout.
-//
-// Structure (one workgroup = 8 waves = one 256 x 256 output tile, K step 64, 1 workgroup per CU):
-//   * Operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction),
-//     two 64 KiB buffers (A tile | W tile).  The LDS image is [row][128 B] with the 16-B chunk index XORed
-//     with (row >> 1) & 7; the DMA writes linearly, so the XOR is applied to each lane's SOURCE address and
-//     again on the fragment read: the ds_read_b128 fragment reads are bank-conflict free and every DMA
-//     instruction still reads 8 whole 128-B lines.
-//   * Each K tile is four phases, one 64 x 32 quadrant of the wave's 128 x 64 output each (16 MFMAs), and
-//     the operand tiles are staged as four "half tiles" named after the quadrant rows/columns they feed
-//     (A-h0/A-h1 = first/second 64 rows of every wave row, W-h0/W-h1 = first/second 32 columns of every
-//     wave column).  A half tile is re-staged two phases after its last read, so the DMA of K tiles t+1 and
-//     t+2 is always in flight under the MFMAs of tile t; one counted s_waitcnt vmcnt per K tile, never 0 in
-//     the steady state.
-//   * The two wave rows (waves 0-3 / 4-7, one of each per SIMD) run half a phase apart: while one does its
-//     16 MFMAs the other issues its LDS reads and DMA, and they swap at every barrier.
-//   * The MFMA is issued with the operands swapped (D^T = W.A^T): the accumulator then has the TOKEN ROW on
-//     the lane and 4 consecutive output columns in consecutive registers, so the epilogue stores 8 B per lane
-//     contiguous in N and bias/gate are per-register constants.
-#include "fp_common.h"
-
-namespace {
-
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int OP_BYTES = BM * BK * 2;        // 32 KiB: one operand tile
-constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ void dma16(const bf16* src, unsigned char* dst) {
-    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
-}
-
-__device__ __forceinline__ float gelu_tanh(float v) {
-    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-    const float e = __expf(2.f * u);
-    const float th = 1.f - 2.f / (e + 1.f);
-    return 0.5f * v * (1.f + th);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16* __restrict__ A, int64_t lda,
-                                                           int64_t a2_delta, int k1,
-                                                           const bf16* __restrict__ W, int64_t ldw,
-                                                           const bf16* __restrict__ bias, bf16* __restrict__ C,
-                                                           int64_t ldc, int M, int N, int K, int gelu_from,
-                                                           const bf16* __restrict__ R, int64_t ldr,
-                                                           const bf16* __restrict__ gate, int ntm, int ntn) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2][A 32 KiB | W 32 KiB]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-
-    // tile order: XCD-contiguous, grouped 8 row-tiles tall so that co-running tiles share A and W panels
-    constexpr int GM = 8;
-    const int wid = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_group = GM * ntn;
-    const int group = wid / per_group, in_group = wid % per_group;
-    const int first_m = group * GM;
-    const int gsz = min(ntm - first_m, GM);
-    const int tm = first_m + in_group % gsz, tn = in_group / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    // ---- DMA source pointers: operand x half x instruction.  One instruction = 8 tile rows x 128 B.
-    const int prow = lane >> 3, pch = lane & 7;
-    const bf16* pa[2][2];
-    const bf16* pw[2][2];
-    int arow0[2][2], wrow0[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            arow0[h][j] = j * 128 + h * 64 + wave * 8;
-            const int p = wave + 8 * j;
-            wrow0[h][j] = (p >> 2) * 64 + h * 32 + (p & 3) * 8;
-            const int ar = arow0[h][j] + prow, wrw = wrow0[h][j] + prow;
-            pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + ((pch ^ ((ar >> 1) & 7)) << 3);
-            pw[h][j] = W + (int64_t)min(n0 + wrw, N - 1) * ldw + ((pch ^ ((wrw >> 1) & 7)) << 3);
-        }
-    auto issue_a = [&](int h, int t) {
-        const int64_t koff = (int64_t)t * BK + ((t * BK >= k1) ? a2_delta : 0);
-        unsigned char* dst = smem + (t & 1) * BUF_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(pa[h][j] + koff, dst + arow0[h][j] * 128);
-    };
-    auto issue_w = [&](int h, int t) {
-        const int64_t koff = (int64_t)t * BK;
-        unsigned char* dst = smem + (t & 1) * BUF_BYTES + OP_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) dma16(pw[h][j] + koff, dst + wrow0[h][j] * 128);
-    };
-
-    // ---- fragment read offsets: lane reads tile row (lane & 15), chunk 4 ks + (lane >> 4), swizzled
-    const int fr = lane & 15, fq = lane >> 4;
-    const unsigned off_k0 = (unsigned)(fr * 128 + ((fq ^ (fr >> 1)) << 4));     // ks = 1: off_k0 ^ 64
-    const unsigned char* a_rd0 = smem + (wr * 128) * 128 + off_k0;
-    const unsigned char* a_rd1 = smem + (wr * 128) * 128 + (off_k0 ^ 64);
-    const unsigned char* w_rd0 = smem + OP_BYTES + (wc * 64) * 128 + off_k0;
-    const unsigned char* w_rd1 = smem + OP_BYTES + (wc * 64) * 128 + (off_k0 ^ 64);
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], wf[2][2];
-
-    const int nk = K / BK;
-
-    // ---- prologue: tile 0 whole, then the two half tiles of tile 1 that the loop does not issue itself
-    issue_a(0, 0);
-    issue_w(0, 0);
-    issue_w(1, 0);
-    issue_a(1, 0);
-    if (nk > 1) {
-        issue_a(0, 1);
-        issue_w(1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    if (wr == 1) __builtin_amdgcn_s_barrier();        // second wave row runs one barrier behind
-
-#define FP_LDS_A(BUF, MH)                                                                                     \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                        \
-        const int o_ = (BUF) * BUF_BYTES + ((MH) * 64 + mi * 16) * 128;                                       \
-        af[mi][0] = *reinterpret_cast<const bf16x8*>(a_rd0 + o_);                                             \
-        af[mi][1] = *reinterpret_cast<const bf16x8*>(a_rd1 + o_);                                             \
-    }
-#define FP_LDS_W(BUF, NH)                                                                                     \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                        \
-        const int o_ = (BUF) * BUF_BYTES + ((NH) * 32 + ni * 16) * 128;                                       \
-        wf[ni][0] = *reinterpret_cast<const bf16x8*>(w_rd0 + o_);                                             \
-        wf[ni][1] = *reinterpret_cast<const bf16x8*>(w_rd1 + o_);                                             \
-    }
-#define FP_MFMA_QUAD(MH, NH)                                                                                  \
-    __builtin_amdgcn_s_barrier();                                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    __builtin_amdgcn_s_setprio(1);                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                      \
-            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
-                acc[(MH) * 4 + mi][(NH) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-                    wf[ni][ks], af[mi][ks], acc[(MH) * 4 + mi][(NH) * 2 + ni], 0, 0, 0);                      \
-    __builtin_amdgcn_s_setprio(0);                                                                            \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    __builtin_amdgcn_s_barrier();                                                                             \
-    __builtin_amdgcn_sched_barrier(0);
-
-    // One K tile = four phases.  BUF is the LDS buffer of tile t (a literal so that addresses fold).
-#define FP_KTILE(BUF, t)                                                                                      \
-    {                                                                                                         \
-        /* q0: quadrant (0,0) */                                                                              \
-        FP_LDS_W(BUF, 0)                                                                                      \
-        FP_LDS_A(BUF, 0)                                                                                      \
-        if ((t) + 1 < nk) issue_a(1, (t) + 1);                                                                \
-        FP_MFMA_QUAD(0, 0)                                                                                    \
-        /* q1: quadrant (0,1) */                                                                              \
-        FP_LDS_W(BUF, 1)                                                                                      \
-        if ((t) + 1 < nk) issue_w(0, (t) + 1);                                                                \
-        FP_MFMA_QUAD(0, 1)                                                                                    \
-        /* q2: quadrant (1,1) */                                                                              \
-        FP_LDS_A(BUF, 1)                                                                                      \
-        if ((t) + 2 < nk) issue_a(0, (t) + 2);                                                                \
-        FP_MFMA_QUAD(1, 1)                                                                                    \
-        /* q3: quadrant (1,0); the wait retires tile t+1 for the next phase */                                \
-        FP_LDS_W(BUF, 0)                                                                                      \
-        if ((t) + 2 < nk) {                                                                                   \
-            issue_w(1, (t) + 2);                                                                              \
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                  \
-        } else {                                                                                              \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-        }                                                                                                     \
-        FP_MFMA_QUAD(1, 0)                                                                                    \
-    }
-
-    int t = 0;
-    for (; t + 1 < nk; t += 2) {
-        FP_KTILE(0, t)
-        FP_KTILE(1, t + 1)
-    }
-    if (t < nk) FP_KTILE(0, t)
-    if (wr == 0) __builtin_amdgcn_s_barrier();
-#undef FP_KTILE
-#undef FP_MFMA_QUAD
-#undef FP_LDS_W
-#undef FP_LDS_A
-
-    // ---- epilogue: lane (fr,fq) holds row m = m0 + wr*128 + mi*16 + fr, columns n0 + wc*64 + ni*16 + 4 fq + (0..3)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wc * 64 + ni * 16 + 4 * fq;
-        if (n >= N) continue;
-        bf16x4 bv = {0, 0, 0, 0};
-        if (bias) bv = *reinterpret_cast<const bf16x4*>(bias + n);
-        bf16x4 gv = {0, 0, 0, 0};
-        if (EPI == 3) gv = *reinterpret_cast<const bf16x4*>(gate + n);
-        const bool do_gelu = EPI == 1 || (EPI == 2 && n >= gelu_from);
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + wr * 128 + mi * 16 + fr;
-            if (m >= M) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + (float)bv[j];
-            if (do_gelu) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
-            }
-            if (EPI == 3) {
-                const bf16x4 rv = *reinterpret_cast<const bf16x4*>(R + (int64_t)m * ldr + n);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (float)rv[j] + (float)gv[j] * v[j];
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
-            *reinterpret_cast<bf16x4*>(C + (int64_t)m * ldc + n) = o;
-        }
-    }
-}
-
-template <int EPI>
-int launch(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
-           void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
-           const void* gate, hipStream_t st) {
-    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
-    constexpr int smem = 2 * BUF_BYTES;
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-    gemm_bf16_kernel<EPI><<<dim3((unsigned)(ntm * ntn)), dim3(512), smem, st>>>(
-        (const bf16*)a, lda, a2_delta, k1, (const bf16*)w, ldw, (const bf16*)bias, (bf16*)c, ldc, M, N, K,
-        gelu_from, (const bf16*)resid, ldr, (const bf16*)gate, ntm, ntn);
-    FP_CHECK_LAUNCH();
-    return 0;
-}
-
-}  // namespace
+// K5: the nn.Linear of every DiT block, bf16 (kernel: gemm_pipeline.h).
+#include "gemm_pipeline.h"
 
 extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
                             const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue,
                             int gelu_from, const void* resid, int64_t ldr, const void* gate, void* stream) {
-    FP_REQUIRE(a && w && c && M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0);
-    FP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && ldw >= K && ldc >= N);
-    FP_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 7) == 0);
-    FP_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0);
-    int64_t a2_delta = 0;
-    if (a2) {
-        FP_REQUIRE(k1 > 0 && k1 < K && k1 % BK == 0 && ((uintptr_t)a2 & 15) == 0 && lda >= k1 && lda >= K - k1);
-        // element offset that turns "A + k" into "A2 + (k - k1)" for k >= k1 (same row stride)
-        a2_delta = ((const bf16*)a2 - (const bf16*)a) - k1;
-    } else {
-        FP_REQUIRE(lda >= K);
-        k1 = K;
-    }
-    FP_REQUIRE(epilogue >= 0 && epilogue <= 3);
-    if (epilogue == 2) FP_REQUIRE(gelu_from >= 0 && gelu_from % 4 == 0);
-    if (epilogue == 3)
-        FP_REQUIRE(resid && gate && ldr % 4 == 0 && ldr >= N && ((uintptr_t)resid & 7) == 0 && ((uintptr_t)gate & 7) == 0);
+    using namespace fp_gemm;
+    int64_t a2_delta;
+    if (int rc = check_dense(a, lda, a2, k1, w, ldw, bias, c, ldc, M, N, K, epilogue, gelu_from, resid, ldr, gate, a2_delta))
+        return rc;
     if (M == 0) return 0;
-    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
+    const ConvGeom cg{};
     hipStream_t st = (hipStream_t)stream;
+#define FP_CASE(E) case E: return launch<bf16, E, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st)
     switch (epilogue) {
-        case 0: return launch<0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, st);
-        case 1: return launch<1>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, st);
-        case 2: return launch<2>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, st);
-        default: return launch<3>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, st);
+        FP_CASE(0);
+        FP_CASE(1);
+        FP_CASE(2);
+        FP_CASE(3);
+        default: FP_CASE(4);
     }
+#undef FP_CASE
 }

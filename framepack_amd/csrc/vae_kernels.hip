@@ -1,0 +1,236 @@
+// K11: kernels of the causal-3D VAE decoder (fp16, channels-last [T, H, W, C] volumes).
+//
+// Replaces what ref diffusers_helper/hunyuan.py:93-103 (vae_decode) reaches inside diffusers 0.33.1's
+// AutoencoderKLHunyuanVideo.decode (third-party, not in the reference tree; restated in oracle/vae_oracle.py):
+//   * HunyuanVideoCausalConv3d 3x3x3 (replicate padding, two frames in front and none behind), optionally
+//     reading its input through the nearest-neighbour upsampling of HunyuanVideoUpsampleCausal3D without
+//     materialising it, with bias and the resnet's residual add in the epilogue  -> implicit GEMM on the
+//     MFMA pipeline of gemm_pipeline.h (the A operand is gathered by LDS-DMA, one tap per K tile);
+//   * 1x1x1 convolutions and the mid-block attention's linears / QK^T / PV                -> dense fp16 GEMM;
+//   * GroupNorm(32) (+SiLU): deterministic two-stage statistics, then one fused normalise+affine+SiLU pass;
+//   * the mid-block attention's frame-causal softmax over materialised scores (one head of 512 channels).
+#include "gemm_pipeline.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+extern "C" int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
+                           const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue,
+                           int gelu_from, const void* resid, int64_t ldr, const void* gate, void* stream) {
+    using namespace fp_gemm;
+    int64_t a2_delta;
+    if (int rc = check_dense(a, lda, a2, k1, w, ldw, bias, c, ldc, M, N, K, epilogue, gelu_from, resid, ldr, gate, a2_delta))
+        return rc;
+    if (M == 0) return 0;
+    const ConvGeom cg{};
+    hipStream_t st = (hipStream_t)stream;
+    switch (epilogue) {
+        case 0: return launch<f16, 0, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
+        case 4: return launch<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
+        default: return (int)hipErrorInvalidValue;      // the VAE uses bias-only and bias+residual
+    }
+}
+
+// y[To,Ho,Wo,Cout] = conv3x3x3_causal_replicate(upsample(x[Ti,Hi,Wi,Cin])) + bias (+ resid)
+// w: [Cout][27][Cin] (tap-major, channel-minor);  up_t/up_h/up_w in {1, 2};  To = up_t == 2 ? 2 Ti - 1 : Ti.
+extern "C" int fp_conv3d_causal_f16(const void* x, const void* w, const void* bias, void* y, int Ti, int Hi, int Wi,
+                                    int up_t, int up_h, int up_w, int Cin, int Cout, const void* resid,
+                                    void* stream) {
+    using namespace fp_gemm;
+    FP_REQUIRE(x && w && y && Ti > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cin % BK == 0 && Cout > 0 && Cout % 8 == 0);
+    FP_REQUIRE((up_t == 1 || up_t == 2) && (up_h == 1 || up_h == 2) && (up_w == 1 || up_w == 2));
+    FP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 7) == 0);
+    FP_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0);
+    FP_REQUIRE(!resid || ((uintptr_t)resid & 7) == 0);
+    ConvGeom cg;
+    cg.Ti = Ti; cg.Hi = Hi; cg.Wi = Wi;
+    cg.To = up_t == 2 ? 2 * Ti - 1 : Ti; cg.Ho = Hi * up_h; cg.Wo = Wi * up_w;
+    cg.Cin = Cin; cg.st = up_t - 1; cg.sh = up_h - 1; cg.sw = up_w - 1;
+    const int64_t M64 = (int64_t)cg.To * cg.Ho * cg.Wo;
+    FP_REQUIRE(M64 < (1ll << 31) && (int64_t)Ti * Hi * Wi * Cin < (1ll << 40));
+    const int M = (int)M64, N = Cout, K = 27 * Cin;
+    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
+    hipStream_t st = (hipStream_t)stream;
+    if (resid)
+        return launch<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st);
+    return launch<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
+}
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+
+// Stage 1 of the GroupNorm statistics: block b sums x and x^2 of its row range per 4-channel quad.
+// x: [rows, C] fp16, C % 8 == 0, C / 8 <= 256 and a power of two.  partial: [gridDim.x][C / 4][2] floats.
+__global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const f16* __restrict__ x, int64_t rows, int C,
+                                                                float* __restrict__ partial) {
+    __shared__ float red[GN_THREADS * 4];
+    const int chunks = C >> 3;                       // 16-B chunks per row
+    const int rpi = GN_THREADS / chunks;             // rows per iteration of the block
+    const int c8 = threadIdx.x % chunks, rl = threadIdx.x / chunks;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * rpi + rl; r < rows; r += (int64_t)gridDim.x * rpi) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(x + r * C + c8 * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = (float)v[j], b = (float)v[4 + j];
+            s0 += a; q0 += a * a; s1 += b; q1 += b * b;
+        }
+    }
+    red[threadIdx.x * 4 + 0] = s0; red[threadIdx.x * 4 + 1] = q0;
+    red[threadIdx.x * 4 + 2] = s1; red[threadIdx.x * 4 + 3] = q1;
+    __syncthreads();
+    if (rl == 0) {                                   // fixed-order sum over the block's row lanes
+        for (int i = 1; i < rpi; ++i) {
+            const float* p = red + (i * chunks + c8) * 4;
+            s0 += p[0]; q0 += p[1]; s1 += p[2]; q1 += p[3];
+        }
+        float* o = partial + ((int64_t)blockIdx.x * (C >> 2) + c8 * 2) * 2;
+        o[0] = s0; o[1] = q0; o[2] = s1; o[3] = q1;
+    }
+}
+
+// Stage 2: stats[g] = (mean, rstd) of group g (C / groups channels), partials summed in block order.
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int groups, int64_t rows,
+                                   float eps, float* __restrict__ stats) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const int quads = (C / groups) >> 2;             // 4-channel quads per group
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b)
+        for (int i = 0; i < quads; ++i) {
+            const float* p = partial + ((int64_t)b * (C >> 2) + g * quads + i) * 2;
+            s += p[0]; q += p[1];
+        }
+    const double n = (double)rows * (C / groups);
+    const double mean = s / n;
+    const double var = fmax(q / n - mean * mean, 0.0);
+    stats[2 * g] = (float)mean;
+    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = f((x - mean_g) * rstd_g * gamma_c + beta_c),  f = SiLU or identity
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t n8,
+                                                       int C, int groups, const float* __restrict__ stats,
+                                                       const f16* __restrict__ gamma, const f16* __restrict__ beta) {
+    const int chunks = C >> 3, gs = C / groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % chunks) * 8;
+        const f16x8 v = *reinterpret_cast<const f16x8*>(x + i * 8);
+        const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c0);
+        const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c0);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c0 + j) / gs;
+            float t = ((float)v[j] - stats[2 * g]) * stats[2 * g + 1] * (float)gm[j] + (float)bt[j];
+            if (SILU) t = t / (1.f + __expf(-t));
+            o[j] = (f16)t;
+        }
+        *reinterpret_cast<f16x8*>(y + i * 8) = o;
+    }
+}
+
+// In-place softmax of row i over columns [0, (i / tokens_per_frame + 1) * tokens_per_frame) of scale * s;
+// the other columns up to `cols` are written as 0.  One workgroup per row; two passes over the row.
+__global__ __launch_bounds__(256) void softmax_framecausal_kernel(f16* __restrict__ s, int64_t ld, int cols,
+                                                                  int tokens_per_frame, float scale_log2e) {
+    __shared__ float red[8];
+    const int row = blockIdx.x;
+    f16* p = s + (int64_t)row * ld;
+    const int valid = min((row / tokens_per_frame + 1) * tokens_per_frame, cols);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY, l = 0.f;
+    for (int c = threadIdx.x * 8; c < valid; c += 256 * 8) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(p + c);
+        float mx = (float)v[0];                                        // column c < valid
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, c + j < valid ? (float)v[j] : -INFINITY);
+        const float mn = fmaxf(m, mx * scale_log2e);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc += c + j < valid ? __builtin_amdgcn_exp2f((float)v[j] * scale_log2e - mn) : 0.f;
+        l = l * __builtin_amdgcn_exp2f(m - mn) + acc;
+        m = mn;
+    }
+    // combine (m, l) over the workgroup
+    float mw = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
+    if (lane == 0) red[wave] = mw;
+    __syncthreads();
+    const float mt = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lw = (m == -INFINITY) ? 0.f : l * __builtin_amdgcn_exp2f(m - mt);
+    lw = wave_sum(lw);
+    __syncthreads();
+    if (lane == 0) red[4 + wave] = lw;
+    __syncthreads();
+    const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+        f16x8 o;
+        if (c < valid) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(p + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[j] = c + j < valid ? (f16)(__builtin_amdgcn_exp2f((float)v[j] * scale_log2e - mt) * inv) : (f16)0.f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+        }
+        *reinterpret_cast<f16x8*>(p + c) = o;
+    }
+}
+
+}  // namespace
+
+// GroupNorm statistics of x [rows, C] (channels-last volume flattened): stats[g] = (mean, rstd), fp32.
+// workspace: >= fp_groupnorm_workspace_floats(C) floats of device memory (fully overwritten by the call).
+extern "C" int fp_groupnorm_workspace_floats(int C) { return 1024 * (C / 4) * 2; }
+
+extern "C" int fp_groupnorm_stats_f16(const void* x, int64_t rows, int C, int groups, float eps, float* workspace,
+                                      float* stats, void* stream) {
+    FP_REQUIRE(x && workspace && stats && rows > 0 && C > 0 && groups > 0 && C % groups == 0 && (C / groups) % 4 == 0);
+    FP_REQUIRE(C % 8 == 0 && (C / 8) <= GN_THREADS && ((C / 8) & (C / 8 - 1)) == 0 && ((uintptr_t)x & 15) == 0);
+    const int rpi = GN_THREADS / (C / 8);
+    const int nblocks = (int)((rows + rpi - 1) / rpi < 1024 ? (rows + rpi - 1) / rpi : 1024);
+    hipStream_t st = (hipStream_t)stream;
+    gn_partial_kernel<<<dim3(nblocks), dim3(GN_THREADS), 0, st>>>((const f16*)x, rows, C, workspace);
+    FP_CHECK_LAUNCH();
+    gn_finalize_kernel<<<dim3((groups + 63) / 64), dim3(64), 0, st>>>(workspace, nblocks, C, groups, rows, eps, stats);
+    FP_CHECK_LAUNCH();
+    return 0;
+}
+
+// y = f(GroupNorm(x; stats) * gamma + beta), f = SiLU (silu != 0) or identity; y may alias x.
+extern "C" int fp_groupnorm_apply_f16(const void* x, void* y, int64_t rows, int C, int groups, const float* stats,
+                                      const void* gamma, const void* beta, int silu, void* stream) {
+    FP_REQUIRE(x && y && stats && gamma && beta && rows > 0 && C % 8 == 0 && groups > 0 && C % groups == 0);
+    FP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
+               ((uintptr_t)beta & 15) == 0);
+    const int64_t n8 = rows * (C / 8);
+    const int nblocks = (int)(n8 / 256 + 1 < 8192 ? n8 / 256 + 1 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (silu)
+        gn_apply_kernel<true><<<dim3(nblocks), dim3(256), 0, st>>>((const f16*)x, (f16*)y, n8, C, groups, stats,
+                                                                   (const f16*)gamma, (const f16*)beta);
+    else
+        gn_apply_kernel<false><<<dim3(nblocks), dim3(256), 0, st>>>((const f16*)x, (f16*)y, n8, C, groups, stats,
+                                                                    (const f16*)gamma, (const f16*)beta);
+    FP_CHECK_LAUNCH();
+    return 0;
+}
+
+// In-place frame-causal softmax of the mid-block attention scores s [rows, cols] (row stride ld): token i may
+// attend to the tokens of frames <= its own (prepare_causal_attention_mask of the diffusers VAE).
+extern "C" int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int tokens_per_frame, float scale,
+                                          void* stream) {
+    FP_REQUIRE(s && rows >= 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 8 == 0 && tokens_per_frame > 0);
+    FP_REQUIRE(((uintptr_t)s & 15) == 0);
+    if (rows == 0) return 0;
+    softmax_framecausal_kernel<<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(
+        (f16*)s, ld, cols, tokens_per_frame, scale * 1.4426950408889634f);
+    FP_CHECK_LAUNCH();
+    return 0;
+}

@@ -24,6 +24,12 @@ SIGNATURES = {
     "fp_silu_gemv_bf16": [P, P, P, P, I, I, I, P],
     "fp_rel_l1_bf16": [P, P, L, P, P],
     "fp_gemm_bf16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
+    "fp_gemm_f16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
+    "fp_conv3d_causal_f16": [P, P, P, P, I, I, I, I, I, I, I, I, P, P],
+    "fp_groupnorm_workspace_floats": [I],
+    "fp_groupnorm_stats_f16": [P, L, I, I, F, P, P, P],
+    "fp_groupnorm_apply_f16": [P, P, L, I, I, P, P, P, I, P],
+    "fp_softmax_framecausal_f16": [P, I, I, L, I, F, P],
 }
 
 _lib = None

@@ -6,13 +6,14 @@ strides to libframepack_hip.so.  CPU tensors are rejected: there is no fallback 
 from __future__ import annotations
 
 import math
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 
 from . import lib as _lib
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 
 # bench.py sets this to a list to time the dominant kernel live: every attention launch is then bracketed by
 # two events recorded on the stream it is launched on (appended as (start, end, tokens, heads)).
@@ -157,7 +158,7 @@ def rel_l1(a: torch.Tensor, b: torch.Tensor, acc: Optional[torch.Tensor] = None)
     return acc
 
 
-EPI_BIAS, EPI_GELU, EPI_GELU_FROM, EPI_GATE_RESIDUAL = 0, 1, 2, 3
+EPI_BIAS, EPI_GELU, EPI_GELU_FROM, EPI_GATE_RESIDUAL, EPI_RESIDUAL = 0, 1, 2, 3, 4
 
 
 def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None,
@@ -174,21 +175,82 @@ def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
         assert M2 == M and lda2 == lda and K1 + K2 == K
     else:
         assert K1 == K, f"A has K={K1}, weight has K={K}"
-    assert a.dtype == BF16 and weight.dtype == BF16 and (bias is None or (bias.dtype == BF16 and bias.numel() == N))
+    dt = a.dtype
+    assert dt in (BF16, F16) and weight.dtype == dt and (bias is None or (bias.dtype == dt and bias.numel() == N))
     if out is None:
-        out = torch.empty((M, N), dtype=BF16, device=a.device)
+        out = torch.empty((M, N), dtype=dt, device=a.device)
     o_, Mo, No, ldc = _rows2d(out)
-    assert (Mo, No) == (M, N) and out.dtype == BF16
+    assert (Mo, No) == (M, N) and out.dtype == dt
     ldr = 0
-    if epilogue == EPI_GATE_RESIDUAL:
+    rptr, gptr = None, None
+    if epilogue in (EPI_GATE_RESIDUAL, EPI_RESIDUAL):
         r_, Mr, Nr, ldr = _rows2d(resid)
-        assert (Mr, Nr) == (M, N) and resid.dtype == BF16
+        assert (Mr, Nr) == (M, N) and resid.dtype == dt
+        rptr = r_.data_ptr()
+    if epilogue == EPI_GATE_RESIDUAL:
         gate = gate.reshape(-1).contiguous()
-        assert gate.numel() == N and gate.dtype == BF16
-        rptr, gptr = r_.data_ptr(), gate.data_ptr()
-    else:
-        rptr, gptr = None, None
-    _lib.check(_lib.load().fp_gemm_bf16(a_.data_ptr(), lda, None if a2 is None else a2_.data_ptr(), k1, w_.data_ptr(), ldw,
+        assert gate.numel() == N and gate.dtype == dt
+        gptr = gate.data_ptr()
+    fn = _lib.load().fp_gemm_bf16 if dt == BF16 else _lib.load().fp_gemm_f16
+    _lib.check(fn(a_.data_ptr(), lda, None if a2 is None else a2_.data_ptr(), k1, w_.data_ptr(), ldw,
                                         _ptr(bias), o_.data_ptr(), ldc, M, N, K, epilogue, gelu_from, rptr, ldr, gptr,
-                                        _stream(a)), "fp_gemm_bf16")
+               _stream(a)), "fp_gemm_bf16" if dt == BF16 else "fp_gemm_f16")
     return out
+
+
+# ---- K11: causal-3D VAE decode (fp16, channels-last volumes) ------------------------------------------------
+
+def conv3d_causal(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                  up: Tuple[int, int, int] = (1, 1, 1), resid: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal 3x3x3 convolution with replicate padding.  x [T,H,W,Cin] fp16 contiguous, weight [Cout, 27*Cin]
+    (tap-major), `up` = nearest-upsampling factors applied on the fly to x (first frame not doubled in time)."""
+    _dev(x, weight, bias, resid, out)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == F16 and weight.dtype == F16 and weight.is_contiguous()
+    Ti, Hi, Wi, Cin = x.shape
+    Cout = weight.shape[0]
+    assert weight.shape[1] == 27 * Cin
+    To = 2 * Ti - 1 if up[0] == 2 else Ti
+    shape = (To, Hi * up[1], Wi * up[2], Cout)
+    if out is None:
+        out = torch.empty(shape, dtype=F16, device=x.device)
+    assert tuple(out.shape) == shape and out.is_contiguous() and out.dtype == F16
+    if resid is not None:
+        assert tuple(resid.shape) == shape and resid.is_contiguous() and resid.dtype == F16
+    if bias is not None:
+        assert bias.dtype == F16 and bias.numel() == Cout and bias.is_contiguous()
+    _lib.check(_lib.load().fp_conv3d_causal_f16(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), Ti, Hi, Wi,
+                                                up[0], up[1], up[2], Cin, Cout, _ptr(resid), _stream(x)),
+               "fp_conv3d_causal_f16")
+    return out
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-6,
+              silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+SiLU) over a channels-last volume x [..., C] fp16 (all leading dims are the group's extent)."""
+    _dev(x, gamma, beta, out)
+    assert x.is_contiguous() and x.dtype == F16 and gamma.dtype == F16 and beta.dtype == F16
+    C = x.shape[-1]
+    rows = x.numel() // C
+    lib = _lib.load()
+    ws = torch.empty((lib.fp_groupnorm_workspace_floats(C),), dtype=torch.float32, device=x.device)
+    stats = torch.empty((2 * groups,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.fp_groupnorm_stats_f16(x.data_ptr(), rows, C, groups, eps, ws.data_ptr(), stats.data_ptr(),
+                                          _stream(x)), "fp_groupnorm_stats_f16")
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.shape == x.shape and out.is_contiguous() and out.dtype == F16
+    _lib.check(lib.fp_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), rows, C, groups, stats.data_ptr(),
+                                          gamma.data_ptr(), beta.data_ptr(), int(silu), _stream(x)),
+               "fp_groupnorm_apply_f16")
+    return out
+
+
+def softmax_framecausal_(scores: torch.Tensor, tokens_per_frame: int, scale: float) -> torch.Tensor:
+    """In-place frame-causal softmax of scores [rows, cols] fp16 (row stride = cols)."""
+    _dev(scores)
+    assert scores.dim() == 2 and scores.is_contiguous() and scores.dtype == F16
+    _lib.check(_lib.load().fp_softmax_framecausal_f16(scores.data_ptr(), scores.shape[0], scores.shape[1],
+                                                      scores.stride(0), tokens_per_frame, scale, _stream(scores)),
+               "fp_softmax_framecausal_f16")
+    return scores

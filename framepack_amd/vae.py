@@ -1,0 +1,349 @@
+"""Host mirror of the VAE decode boundary: `AutoencoderKLHunyuanVideo.decode` + `vae_decode`.
+
+The reference's code for this path is ref: diffusers_helper/hunyuan.py:93-103 (`vae_decode`) and :61-89
+(`vae_decode_fake`); the model class itself is diffusers 0.33.1's `AutoencoderKLHunyuanVideo`
+(ref: framepack/models.py:158-163 constructs it with `from_pretrained(..., subfolder='vae', torch_dtype=float16)`).
+This module keeps that class name, its parameter names (`decoder.*`, `post_quant_conv.*`, so a real checkpoint's
+decoder half loads unchanged), `.config.scaling_factor`, `.dtype/.device` and `decode(z).sample`, and runs the
+decoder on the gfx950 kernels of csrc/vae_kernels.hip: volumes are fp16 channels-last [T, H, W, C], every 3x3x3
+convolution is an implicit GEMM, nearest upsampling is folded into the following convolution's gather,
+GroupNorm+SiLU is one fused pass after a deterministic statistics pass, the resnet skip is added in the
+convolution's epilogue, and the mid-block attention (one head of 512 channels, frame-causal) runs as
+GEMM -> masked softmax -> GEMM on materialised scores (288 GB of HBM make that the simple choice).
+
+PARITY UNPINNED: the diffusers source is not available offline; the algorithm is the one restated in
+oracle/vae_oracle.py (see its header).  The encoder half (`vae_encode`, run once per job) is not built.
+There is no CPU path: `decode` raises for CPU tensors.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+F16 = torch.float16
+
+
+class _CausalConv3d(nn.Module):
+    """Parameter container with diffusers' names: `<name>.conv.{weight,bias}`."""
+
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, k)
+
+
+class _Resnet(nn.Module):
+    def __init__(self, cin: int, cout: int, groups: int):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=1e-6)
+        self.conv1 = _CausalConv3d(cin, cout, 3)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=1e-6)
+        self.conv2 = _CausalConv3d(cout, cout, 3)
+        if cin != cout:
+            self.conv_shortcut = _CausalConv3d(cin, cout, 1)
+
+
+class _Attention(nn.Module):
+    def __init__(self, c: int, groups: int):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, c, eps=1e-6)
+        self.to_q, self.to_k, self.to_v = nn.Linear(c, c), nn.Linear(c, c), nn.Linear(c, c)
+        self.to_out = nn.ModuleList([nn.Linear(c, c), nn.Dropout(0.0)])
+
+
+class _MidBlock(nn.Module):
+    def __init__(self, c: int, groups: int, add_attention: bool):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(c, c, groups), _Resnet(c, c, groups)])
+        self.attentions = nn.ModuleList([_Attention(c, groups) if add_attention else None])
+
+
+class _Upsample(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = _CausalConv3d(c, c, 3)
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, layers: int, groups: int, factor: Optional[Tuple[int, int, int]]):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if j == 0 else cout, cout, groups) for j in range(layers)])
+        self.factor = factor
+        if factor is not None:
+            self.upsamplers = nn.ModuleList([_Upsample(cout)])
+
+
+class _Decoder(nn.Module):
+    def __init__(self, latent: int, out_ch: int, chans: Tuple[int, ...], layers: int, groups: int, add_attention: bool,
+                 plan: List[Tuple[int, int, Optional[Tuple[int, int, int]]]]):
+        super().__init__()
+        self.conv_in = _CausalConv3d(latent, chans[-1], 3)
+        self.mid_block = _MidBlock(chans[-1], groups, add_attention)
+        self.up_blocks = nn.ModuleList([_UpBlock(ci, co, layers + 1, groups, f) for ci, co, f in plan])
+        self.conv_norm_out = nn.GroupNorm(groups, chans[0], eps=1e-6)
+        self.conv_out = _CausalConv3d(chans[0], out_ch, 3)
+
+
+def _up_block_plan(chans: Tuple[int, ...], spatial_ratio: int, temporal_ratio: int):
+    """Which up block upsamples what (diffusers HunyuanVideoDecoder3D.__init__): with ratios 8/4 and four blocks,
+    block 0 doubles H,W, blocks 1 and 2 double T,H,W, block 3 nothing."""
+    import math
+    rev = list(reversed(chans))
+    n, n_sp, n_t = len(rev), int(math.log2(spatial_ratio)), int(math.log2(temporal_ratio))
+    plan, out_ch = [], rev[0]
+    for i in range(n):
+        prev, out_ch = out_ch, rev[i]
+        sp = i < n_sp
+        tm = (i >= n - 1 - n_t) and i != n - 1
+        plan.append((prev, out_ch, ((2 if tm else 1), (2 if sp else 1), (2 if sp else 1)) if (sp or tm) else None))
+    return plan
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+class DecoderOutput(SimpleNamespace):
+    pass
+
+
+class AutoencoderKLHunyuanVideo(nn.Module):
+    """Decode half of diffusers' AutoencoderKLHunyuanVideo on MI355X kernels (see module docstring)."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 16,
+                 block_out_channels: Tuple[int, ...] = (128, 256, 512, 512), layers_per_block: int = 2,
+                 norm_num_groups: int = 32, scaling_factor: float = 0.476986, spatial_compression_ratio: int = 8,
+                 temporal_compression_ratio: int = 4, mid_block_add_attention: bool = True):
+        super().__init__()
+        self.config = SimpleNamespace(
+            in_channels=in_channels, out_channels=out_channels, latent_channels=latent_channels,
+            block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+            norm_num_groups=norm_num_groups, scaling_factor=scaling_factor,
+            spatial_compression_ratio=spatial_compression_ratio, temporal_compression_ratio=temporal_compression_ratio,
+            mid_block_add_attention=mid_block_add_attention)
+        plan = _up_block_plan(tuple(block_out_channels), spatial_compression_ratio, temporal_compression_ratio)
+        self.decoder = _Decoder(latent_channels, out_channels, tuple(block_out_channels), layers_per_block,
+                                norm_num_groups, mid_block_add_attention, plan)
+        self.post_quant_conv = nn.Conv3d(latent_channels, latent_channels, 1)
+        # diffusers defaults: framewise (temporally tiled) decoding on, spatial tiling / slicing off
+        self.use_framewise_decoding = True
+        self.tile_sample_min_num_frames = 16
+        self.tile_sample_stride_num_frames = 12
+        self._prep: Optional[Dict[str, torch.Tensor]] = None
+        self._prep_key = None
+
+    # ---- reference-visible attributes -----------------------------------------------------------------------
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.post_quant_conv.weight.dtype
+
+    @property
+    def device(self) -> torch.device:
+        return self.post_quant_conv.weight.device
+
+    def enable_slicing(self) -> None:      # low-VRAM knobs of the reference (models.py:280-282): not needed here
+        pass
+
+    def enable_tiling(self) -> None:
+        pass
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        """A full diffusers checkpoint also holds `encoder.*` / `quant_conv.*`; the encode half is not built, so
+        those keys are dropped before the strict check of the decode half."""
+        sd = {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
+        self._prep = None
+        return super().load_state_dict(sd, strict=strict, assign=assign)
+
+    def _apply(self, fn, *a, **kw):
+        self._prep = None
+        return super()._apply(fn, *a, **kw)
+
+    # ---- weight preparation -----------------------------------------------------------------------------------
+    def _prepare(self) -> Dict[str, torch.Tensor]:
+        key = (self.post_quant_conv.weight.data_ptr(), self.post_quant_conv.weight._version)
+        if self._prep is not None and self._prep_key == key:
+            return self._prep
+        dev = self.device
+        W: Dict[str, torch.Tensor] = {}
+
+        def conv3(name: str, m: _CausalConv3d) -> None:
+            w = m.conv.weight.detach().to(dev, F16)                           # [Cout, Cin, 3, 3, 3]
+            cout, cin = w.shape[:2]
+            cinp, coutp = _pad_to(cin, 64), _pad_to(cout, 8)
+            wp = torch.zeros(coutp, 27, cinp, dtype=F16, device=dev)
+            wp[:cout, :, :cin] = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin)
+            bp = torch.zeros(coutp, dtype=F16, device=dev)
+            bp[:cout] = m.conv.bias.detach().to(dev, F16)
+            W[name + ".w"], W[name + ".b"] = wp.reshape(coutp, 27 * cinp).contiguous(), bp
+
+        def norm(name: str, m: nn.GroupNorm) -> None:
+            W[name + ".g"] = m.weight.detach().to(dev, F16).contiguous()
+            W[name + ".b"] = m.bias.detach().to(dev, F16).contiguous()
+
+        def resnet(name: str, m: _Resnet) -> None:
+            norm(name + ".norm1", m.norm1)
+            conv3(name + ".conv1", m.conv1)
+            norm(name + ".norm2", m.norm2)
+            conv3(name + ".conv2", m.conv2)
+            if hasattr(m, "conv_shortcut"):
+                w = m.conv_shortcut.conv.weight.detach().to(dev, F16)
+                W[name + ".sc.w"] = w.reshape(w.shape[0], w.shape[1]).contiguous()
+                W[name + ".sc.b"] = m.conv_shortcut.conv.bias.detach().to(dev, F16).contiguous()
+
+        d = self.decoder
+        lat = self.config.latent_channels
+        # post_quant_conv as a [64, 64] GEMM whose zero-padded output feeds conv_in (Cin padded 16 -> 64)
+        latp = _pad_to(lat, 64)
+        wpq = torch.zeros(latp, latp, dtype=F16, device=dev)
+        wpq[:lat, :lat] = self.post_quant_conv.weight.detach().to(dev, F16).reshape(lat, lat)
+        bpq = torch.zeros(latp, dtype=F16, device=dev)
+        bpq[:lat] = self.post_quant_conv.bias.detach().to(dev, F16)
+        W["pq.w"], W["pq.b"] = wpq, bpq
+        conv3("conv_in", d.conv_in)
+        resnet("mid.0", d.mid_block.resnets[0])
+        resnet("mid.1", d.mid_block.resnets[1])
+        att = d.mid_block.attentions[0]
+        if att is not None:
+            c = att.to_q.weight.shape[0]
+            norm("attn.gn", att.group_norm)
+            scale = c ** -0.5                      # one head of c channels; folded into the q projection
+            wq = (att.to_q.weight.detach().float() * scale).to(dev, F16)
+            bq = (att.to_q.bias.detach().float() * scale).to(dev, F16)
+            W["attn.qkv.w"] = torch.cat([wq, att.to_k.weight.detach().to(dev, F16), att.to_v.weight.detach().to(dev, F16)]).contiguous()
+            W["attn.qkv.b"] = torch.cat([bq, att.to_k.bias.detach().to(dev, F16), att.to_v.bias.detach().to(dev, F16)]).contiguous()
+            W["attn.o.w"] = att.to_out[0].weight.detach().to(dev, F16).contiguous()
+            W["attn.o.b"] = att.to_out[0].bias.detach().to(dev, F16).contiguous()
+        for i, ub in enumerate(d.up_blocks):
+            for j, r in enumerate(ub.resnets):
+                resnet(f"up.{i}.{j}", r)
+            if ub.factor is not None:
+                conv3(f"up.{i}.us", ub.upsamplers[0].conv)
+        norm("norm_out", d.conv_norm_out)
+        conv3("conv_out", d.conv_out)
+        self._prep, self._prep_key = W, key
+        return W
+
+    # ---- the decoder on channels-last fp16 volumes ------------------------------------------------------------
+    def _resnet(self, W, name: str, h: torch.Tensor) -> torch.Tensor:
+        g = self.config.norm_num_groups
+        a = ops.groupnorm(h, W[name + ".norm1.g"], W[name + ".norm1.b"], g)
+        c1 = ops.conv3d_causal(a, W[name + ".conv1.w"], W[name + ".conv1.b"])
+        del a
+        ops.groupnorm(c1, W[name + ".norm2.g"], W[name + ".norm2.b"], g, out=c1)
+        if (name + ".sc.w") in W:
+            cin = h.shape[-1]
+            res = ops.gemm(h.reshape(-1, cin), W[name + ".sc.w"], W[name + ".sc.b"]).reshape(*h.shape[:3], -1)
+        else:
+            res = h
+        return ops.conv3d_causal(c1, W[name + ".conv2.w"], W[name + ".conv2.b"], resid=res)
+
+    def _attention(self, W, h: torch.Tensor) -> torch.Tensor:
+        T, H, Wd, C = h.shape
+        S = T * H * Wd
+        Sp = _pad_to(S, 64)
+        x = h.reshape(S, C)
+        hn = ops.groupnorm(h, W["attn.gn.g"], W["attn.gn.b"], self.config.norm_num_groups, silu=False).reshape(S, C)
+        qkv = torch.zeros(Sp, 3 * C, dtype=F16, device=h.device)              # rows >= S stay zero
+        ops.gemm(hn, W["attn.qkv.w"], W["attn.qkv.b"], out=qkv[:S])
+        scores = torch.empty(S, Sp, dtype=F16, device=h.device)
+        ops.gemm(qkv[:S, :C], qkv[:, C:2 * C], None, out=scores)              # q (pre-scaled) . k^T
+        ops.softmax_framecausal_(scores, H * Wd, 1.0)
+        vt = qkv[:, 2 * C:].t().contiguous()                                   # [C, Sp]; padding columns are zero
+        o = ops.gemm(scores, vt, None)
+        del scores
+        out = ops.gemm(o, W["attn.o.w"], W["attn.o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
+        return out.reshape(T, H, Wd, C)
+
+    def _decode_tile(self, z: torch.Tensor) -> torch.Tensor:
+        """z: [1, latent, T, H, W] on the GPU -> [1, 3, 4(T-1)+1, 8H, 8W] fp16."""
+        W = self._prepare()
+        cfg = self.config
+        lat = cfg.latent_channels
+        _, _, T, H, Wd = z.shape
+        x = torch.zeros(T, H, Wd, W["pq.w"].shape[0], dtype=F16, device=z.device)
+        x[..., :lat] = z[0].permute(1, 2, 3, 0).to(F16)
+        x = ops.gemm(x.reshape(-1, x.shape[-1]), W["pq.w"], W["pq.b"]).reshape(x.shape)
+        h = ops.conv3d_causal(x, W["conv_in.w"], W["conv_in.b"])
+        h = self._resnet(W, "mid.0", h)
+        if cfg.mid_block_add_attention:
+            h = self._attention(W, h)
+        h = self._resnet(W, "mid.1", h)
+        for i, ub in enumerate(self.decoder.up_blocks):
+            for j in range(len(ub.resnets)):
+                h = self._resnet(W, f"up.{i}.{j}", h)
+            if ub.factor is not None:
+                h = ops.conv3d_causal(h, W[f"up.{i}.us.w"], W[f"up.{i}.us.b"], up=ub.factor)
+        ops.groupnorm(h, W["norm_out.g"], W["norm_out.b"], cfg.norm_num_groups, out=h)
+        y = ops.conv3d_causal(h, W["conv_out.w"], W["conv_out.b"])            # [To, Ho, Wo, 8]; channels >= 3 are padding
+        return y[..., :cfg.out_channels].permute(3, 0, 1, 2).unsqueeze(0)
+
+    @staticmethod
+    def _blend_t(a: torch.Tensor, b: torch.Tensor, extent: int) -> torch.Tensor:
+        extent = min(a.shape[2], b.shape[2], extent)
+        b = b.clone()
+        for x in range(extent):
+            b[:, :, x] = a[:, :, -extent + x] * (1 - x / extent) + b[:, :, x] * (x / extent)
+        return b
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, return_dict: bool = True):
+        """`vae.decode(latents).sample`.  More than 4 latent frames are decoded in windows of 4+1 latent frames
+        at stride 3 and cross-faded over 4 output frames (diffusers' framewise decoding, on by default)."""
+        if not z.is_cuda:
+            raise RuntimeError("framepack_amd VAE decode runs on the GPU only; there is no CPU fallback")
+        if z.dim() != 5 or z.shape[0] != 1:
+            raise ValueError(f"expected latents [1, C, T, H, W], got {tuple(z.shape)}")
+        tr = self.config.temporal_compression_ratio
+        T = z.shape[2]
+        t_min, t_stride = self.tile_sample_min_num_frames // tr, self.tile_sample_stride_num_frames // tr
+        if not self.use_framewise_decoding or T <= t_min:
+            dec = self._decode_tile(z)
+        else:
+            rows = []
+            for i in range(0, T, t_stride):
+                d = self._decode_tile(z[:, :, i:i + t_min + 1])
+                rows.append(d[:, :, 1:] if i > 0 else d)
+            blend = self.tile_sample_min_num_frames - self.tile_sample_stride_num_frames
+            out = []
+            for i, tile in enumerate(rows):
+                if i > 0:
+                    tile = self._blend_t(rows[i - 1], tile, blend)
+                    out.append(tile[:, :, :self.tile_sample_stride_num_frames])
+                else:
+                    out.append(tile[:, :, :self.tile_sample_stride_num_frames + 1])
+            dec = torch.cat(out, dim=2)[:, :, :(T - 1) * tr + 1]
+        dec = dec.to(self.dtype) if dec.dtype != self.dtype else dec
+        return DecoderOutput(sample=dec) if return_dict else (dec,)
+
+
+@torch.no_grad()
+def vae_decode(latents: torch.Tensor, vae: AutoencoderKLHunyuanVideo, image_mode: bool = False) -> torch.Tensor:
+    """ref: diffusers_helper/hunyuan.py:93-103 (same name, arguments and branches)."""
+    latents = latents / vae.config.scaling_factor
+    if not image_mode:
+        return vae.decode(latents.to(device=vae.device, dtype=vae.dtype)).sample
+    frames = latents.to(device=vae.device, dtype=vae.dtype).unbind(2)
+    return torch.cat([vae.decode(l.unsqueeze(2)).sample for l in frames], dim=2)
+
+
+# latent -> RGB preview factors, ref: diffusers_helper/hunyuan.py:62-81 (data of the reference, "From comfyui")
+_LATENT_RGB_FACTORS = [
+    [-0.0395, -0.0331, 0.0445], [0.0696, 0.0795, 0.0518], [0.0135, -0.0945, -0.0282], [0.0108, -0.0250, -0.0765],
+    [-0.0209, 0.0032, 0.0224], [-0.0804, -0.0254, -0.0639], [-0.0991, 0.0271, -0.0669], [-0.0646, -0.0422, -0.0400],
+    [-0.0696, -0.0595, -0.0894], [-0.0799, -0.0208, -0.0375], [0.1166, 0.1627, 0.0962], [0.1165, 0.0432, 0.0407],
+    [-0.2315, -0.1920, -0.1355], [-0.0270, 0.0401, -0.0821], [-0.0616, -0.0997, -0.0727], [0.0249, -0.0469, -0.1703],
+]
+_LATENT_RGB_BIAS = [0.0259, -0.0192, -0.0761]
+
+
+@torch.no_grad()
+def vae_decode_fake(latents: torch.Tensor) -> torch.Tensor:
+    """ref: diffusers_helper/hunyuan.py:61-89: the per-step preview, a fixed 16 -> 3 projection clamped to [0, 1]
+    (K12 of SURVEY.md 2b: trivial, stays a torch op)."""
+    weight = torch.tensor(_LATENT_RGB_FACTORS, device=latents.device, dtype=latents.dtype).transpose(0, 1)[:, :, None, None, None]
+    bias = torch.tensor(_LATENT_RGB_BIAS, device=latents.device, dtype=latents.dtype)
+    return torch.nn.functional.conv3d(latents, weight, bias=bias).clamp(0.0, 1.0)

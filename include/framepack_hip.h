@@ -74,12 +74,49 @@ int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc2, void* s
  * 133-135, 154-156, 167-169, 552, 570 and diffusers FeedForward at :646-647).
  *   A: [M, K] row stride lda;  W: [N, K] row-major (nn.Linear layout), row stride ldw;  C: [M, N] stride ldc.
  *   epilogue: 0 = bias only; 1 = bias + tanh-GELU; 2 = bias + tanh-GELU on columns >= gelu_from only;
- *             3 = C = R + gate * (A.W^T + bias)  with R: [M, N] stride ldr (may alias C), gate: [N].
+ *             3 = C = R + gate * (A.W^T + bias)  with R: [M, N] stride ldr (may alias C), gate: [N];
+ *             4 = C = R + (A.W^T + bias).
  *   A may be given as two column segments (a2 != NULL): K = k1 + k2, the second segment read from a2
  *   (same row stride) - the cat([attn, mlp]) of :569 without the copy. */
 int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
                  const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
                  const void* resid, int64_t ldr, const void* gate, void* stream);
+
+/* ---- K11: causal-3D VAE decode (fp16, channels-last [T, H, W, C] volumes) -------------------------------
+ * The reference's code for this path is diffusers_helper/hunyuan.py:93-103 (vae_decode); everything under its
+ * `vae.decode(...)` call is diffusers 0.33.1 AutoencoderKLHunyuanVideo (third-party, absent from the reference
+ * tree, restated in oracle/vae_oracle.py: parity unpinned). */
+
+/* Dense fp16 GEMM, same contract as fp_gemm_bf16 (epilogues 0 and 4 only): 1x1x1 convolutions
+ * (post_quant_conv, conv_shortcut) and the mid-block attention's to_q/k/v, QK^T, PV and to_out. */
+int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
+                const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
+                const void* resid, int64_t ldr, const void* gate, void* stream);
+
+/* HunyuanVideoCausalConv3d 3x3x3 as an implicit GEMM: replicate padding, two frames in front and none behind.
+ *   x: [Ti, Hi, Wi, Cin] (Cin % 64 == 0);  w: [Cout][27][Cin] (tap = (dt*3 + dh)*3 + dw), Cout % 8 == 0;
+ *   y: [To, Ho, Wo, Cout] with Ho = Hi*up_h, Wo = Wi*up_w, To = up_t == 2 ? 2*Ti - 1 : Ti: with a factor of 2 the
+ *   convolution reads the nearest-neighbour upsampling of HunyuanVideoUpsampleCausal3D (first frame not doubled
+ *   in time) without materialising it.  bias: [Cout] or NULL.  resid: [To, Ho, Wo, Cout] added to the result
+ *   (the resnet block's skip) or NULL; may alias y. */
+int fp_conv3d_causal_f16(const void* x, const void* w, const void* bias, void* y, int Ti, int Hi, int Wi,
+                         int up_t, int up_h, int up_w, int Cin, int Cout, const void* resid, void* stream);
+
+/* GroupNorm over a channels-last volume x [rows, C] (rows = T*H*W): stats[g] = (mean, rstd) in fp32, computed
+ * in two deterministic stages.  workspace: fp_groupnorm_workspace_floats(C) floats, overwritten. */
+int fp_groupnorm_workspace_floats(int C);
+int fp_groupnorm_stats_f16(const void* x, int64_t rows, int C, int groups, float eps, float* workspace,
+                           float* stats, void* stream);
+/* y = f(GroupNorm(x; stats) * gamma + beta), f = SiLU if silu != 0 (the resnet's norm+swish), else identity
+ * (the attention's group_norm).  y may alias x. */
+int fp_groupnorm_apply_f16(const void* x, void* y, int64_t rows, int C, int groups, const float* stats,
+                           const void* gamma, const void* beta, int silu, void* stream);
+
+/* In-place softmax(scale * s) of the mid-block attention scores s [rows, cols] (row stride ld) under the
+ * frame-causal mask of the VAE (token i sees the tokens of frames <= its own; tokens_per_frame = h*w);
+ * masked and padding columns are written as 0. */
+int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int tokens_per_frame, float scale,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -119,3 +119,50 @@ def test_forward_refuses_cpu_tensors(tiny_model):
 def test_bad_rank_raises_value_error(tiny_model):
     with pytest.raises(ValueError, match="Unexpected hidden_states shape"):
         tiny_model(torch.zeros(2, 2, 2), None, None, None, None, None)
+
+
+# ---------------------------------------------------------------- VAE decode boundary (host logic, no GPU)
+def test_vae_state_dict_names_and_plan_match_oracle_layout():
+    from framepack_amd.vae import AutoencoderKLHunyuanVideo, _up_block_plan
+    from oracle import vae_oracle as VO
+    cfg = VO.VAEConfig()
+    vae = AutoencoderKLHunyuanVideo()
+    want = VO.random_state_dict(VO.VAEConfig(block_out_channels=(32, 32, 64, 64)))      # names only (small)
+    small = AutoencoderKLHunyuanVideo(block_out_channels=(32, 32, 64, 64))
+    assert set(small.state_dict().keys()) == set(want.keys())
+    assert {k: tuple(v.shape) for k, v in small.state_dict().items()} == {k: tuple(v.shape) for k, v in want.items()}
+    assert _up_block_plan(cfg.block_out_channels, 8, 4) == VO.up_block_plan(cfg) == [
+        (512, 512, (1, 2, 2)), (512, 512, (2, 2, 2)), (512, 256, (2, 2, 2)), (256, 128, None)]
+    assert vae.config.scaling_factor == 0.476986 and vae.use_framewise_decoding
+    # a full checkpoint also carries the encode half: those keys are ignored, the decode half stays strict
+    sd = dict(small.state_dict())
+    sd["encoder.conv_in.conv.weight"] = torch.zeros(1)
+    sd["quant_conv.weight"] = torch.zeros(1)
+    small.load_state_dict(sd, strict=True)
+    del sd["decoder.conv_out.conv.bias"]
+    with pytest.raises(RuntimeError):
+        small.load_state_dict(sd, strict=True)
+
+
+def test_vae_decode_refuses_cpu_and_preview_matches_projection():
+    from framepack_amd.vae import AutoencoderKLHunyuanVideo, vae_decode, vae_decode_fake, _LATENT_RGB_FACTORS, _LATENT_RGB_BIAS
+    vae = AutoencoderKLHunyuanVideo(block_out_channels=(32, 32, 64, 64))
+    with pytest.raises(RuntimeError):
+        vae_decode(torch.zeros(1, 16, 1, 2, 2), vae)
+    z = torch.randn(1, 16, 2, 3, 3, generator=torch.Generator().manual_seed(0))
+    want = (torch.einsum("bcthw,cr->brthw", z, torch.tensor(_LATENT_RGB_FACTORS)) +
+            torch.tensor(_LATENT_RGB_BIAS)[None, :, None, None, None]).clamp(0, 1)
+    torch.testing.assert_close(vae_decode_fake(z), want, rtol=1e-5, atol=1e-6)
+
+
+def test_vae_oracle_framewise_equals_whole_decode_when_short():
+    from oracle import vae_oracle as VO
+    cfg = VO.VAEConfig(block_out_channels=(32, 32, 64, 64))
+    P = VO.random_state_dict(cfg)
+    z = torch.randn(1, 16, 4, 2, 2, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(VO.decode(P, cfg, z, framewise=True), VO.decode(P, cfg, z, framewise=False))   # T <= 4: one window
+    z = torch.randn(1, 16, 7, 2, 2, generator=torch.Generator().manual_seed(2))
+    out = VO.decode(P, cfg, z, framewise=True)
+    assert tuple(out.shape) == (1, 3, 25, 16, 16)
+    mask = VO.frame_causal_mask(2, 3, torch.float32)
+    assert mask[:3, 3:].eq(float("-inf")).all() and mask[3:, :].eq(0).all() and mask[:3, :3].eq(0).all()

@@ -1,0 +1,157 @@
+"""K11 parity: the causal-3D VAE decode kernels (through the C ABI) and the whole decoder against the CPU oracle
+(oracle/vae_oracle.py, PARITY UNPINNED: it restates diffusers' AutoencoderKLHunyuanVideo, absent offline).
+
+Tolerances: volumes are fp16 (11 significand bits, rel. rounding 2^-11 = 5e-4); a convolution with fp32
+accumulation is held to rel-L2 <= 2e-3 against an fp32 reference computed from the same fp16 inputs; the
+north-star bound for decoded frames is PSNR >= 40 dB (peak-to-peak 2.0, frames live in [-1, 1])."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from framepack_amd import ops  # noqa: E402
+from framepack_amd.vae import AutoencoderKLHunyuanVideo, vae_decode  # noqa: E402
+from oracle import vae_oracle as VO  # noqa: E402
+
+DEV = "cuda:0"
+H16 = torch.float16
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def psnr(a, b, peak=2.0):
+    mse = ((a.double().cpu() - b.double().cpu()) ** 2).mean().item()
+    return 10 * math.log10(peak * peak / max(mse, 1e-30))
+
+
+def rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator("cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(H16)
+
+
+def prep_w(w):          # [Cout, Cin, 3, 3, 3] -> [Cout, 27 * Cin] tap-major
+    return w.permute(0, 2, 3, 4, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def ref_conv(x_cl, w, b, up=(1, 1, 1), resid=None):
+    """x_cl [T,H,W,C] fp16 -> fp32 reference in channels-last, through the oracle's upsample + causal conv."""
+    x = x_cl.float().permute(3, 0, 1, 2).unsqueeze(0)
+    P = {"c.conv.weight": w.float(), "c.conv.bias": b.float()}
+    if up != (1, 1, 1):
+        y = VO.upsample_causal({"u.conv.conv.weight": w.float(), "u.conv.conv.bias": b.float()}, "u", x, up)
+    else:
+        y = VO.causal_conv3d(P, "c", x)
+    y = y[0].permute(1, 2, 3, 0)
+    return y + resid.float() if resid is not None else y
+
+
+@pytest.mark.parametrize("T,H,W,cin,cout,up,with_res", [
+    (3, 8, 8, 64, 64, (1, 1, 1), False),
+    (2, 5, 7, 128, 72, (1, 1, 1), True),          # ragged M (70 rows) and N tails
+    (1, 16, 20, 64, 256, (1, 1, 1), False),       # single frame: all temporal taps clamp to frame 0
+    (3, 6, 6, 64, 64, (1, 2, 2), False),          # spatial upsampling folded into the gather
+    (3, 5, 6, 64, 128, (2, 2, 2), True),          # temporal + spatial (first frame not doubled)
+    (1, 4, 4, 64, 64, (2, 2, 2), False),          # one frame in: one frame out
+    (5, 40, 40, 128, 128, (1, 1, 1), True),       # several M tiles
+])
+def test_conv3d_causal(T, H, W, cin, cout, up, with_res):
+    x = rand(T, H, W, cin, seed=1)
+    w = rand(cout, cin, 3, 3, 3, seed=2, scale=(27 * cin) ** -0.5)
+    b = rand(cout, seed=3, scale=0.1)
+    To = 2 * T - 1 if up[0] == 2 else T
+    res = rand(To, H * up[1], W * up[2], cout, seed=4) if with_res else None
+    ref = ref_conv(x, w, b, up, res)
+    got = ops.conv3d_causal(x.to(DEV), prep_w(w).to(DEV), b.to(DEV), up=up, resid=None if res is None else res.to(DEV))
+    assert got.dtype == H16 and tuple(got.shape) == tuple(ref.shape)
+    assert rel_l2(got, ref) < 2e-3
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+
+
+def test_conv3d_rejects_bad_arguments():
+    x, w = rand(2, 4, 4, 32).to(DEV), rand(64, 27 * 32).to(DEV)
+    with pytest.raises(ValueError):
+        ops.conv3d_causal(x, w, None)                              # Cin % 64 != 0
+    with pytest.raises(RuntimeError):
+        ops.conv3d_causal(rand(2, 4, 4, 64), rand(64, 27 * 64), None)   # CPU tensors: no fallback
+
+
+@pytest.mark.parametrize("rows_shape,C,groups,silu", [((3, 8, 8), 64, 16, True), ((2, 5, 7), 128, 32, True),
+                                                       ((5, 40, 40), 512, 32, False), ((1, 3, 3), 256, 32, True)])
+def test_groupnorm_silu(rows_shape, C, groups, silu):
+    x = rand(*rows_shape, C, seed=5, scale=2.0) + 0.3
+    g, b = rand(C, seed=6, scale=0.2) + 1, rand(C, seed=7, scale=0.2)
+    xr = x.float().permute(3, 0, 1, 2).unsqueeze(0)
+    ref = F.group_norm(xr, groups, g.float(), b.float(), 1e-6)
+    ref = (F.silu(ref) if silu else ref)[0].permute(1, 2, 3, 0)
+    got = ops.groupnorm(x.to(DEV), g.to(DEV), b.to(DEV), groups, silu=silu)
+    assert rel_l2(got, ref) < 1e-3
+    got2 = ops.groupnorm(x.to(DEV), g.to(DEV), b.to(DEV), groups, silu=silu)
+    assert torch.equal(got, got2)                                   # two-stage statistics are deterministic
+
+
+def test_softmax_framecausal_matches_masked_softmax():
+    T, hw, pad = 3, 24, 8
+    S = T * hw
+    s = rand(S, S + pad, seed=8, scale=3.0)
+    mask = VO.frame_causal_mask(T, hw, torch.float32)
+    ref = torch.softmax(s[:, :S].float() * 0.37 + mask, dim=-1)
+    got = ops.softmax_framecausal_(s.to(DEV).clone(), hw, 0.37)
+    assert rel_l2(got[:, :S], ref) < 2e-3
+    assert got[:, S:].abs().max().item() == 0 and got[:hw, hw:].abs().max().item() == 0
+
+
+def test_gemm_f16_bias_and_residual():
+    a, w, b, r = rand(300, 128, seed=9), rand(72, 128, seed=10, scale=0.1), rand(72, seed=11), rand(300, 72, seed=12)
+    ref = a.float() @ w.float().T + b.float()
+    assert rel_l2(ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV)), ref) < 2e-3
+    got = ops.gemm(a.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops.EPI_RESIDUAL, resid=r.to(DEV))
+    assert rel_l2(got, ref + r.float()) < 2e-3
+
+
+SMALL = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=16)
+
+
+def build(cfg_kw, seed=0):
+    cfg = VO.VAEConfig(**cfg_kw)
+    P = VO.random_state_dict(cfg, seed=seed)
+    P16 = {k: v.to(H16) for k, v in P.items()}
+    vae = AutoencoderKLHunyuanVideo(**cfg_kw)
+    vae.load_state_dict(P16, strict=True)
+    return cfg, {k: v.float() for k, v in P16.items()}, vae.to(DEV, H16).eval()
+
+
+@pytest.mark.parametrize("T,H,W", [(1, 8, 8), (3, 8, 6), (4, 10, 8)])
+def test_decoder_tile_matches_oracle(T, H, W):
+    cfg, P, vae = build(SMALL)
+    z = torch.randn(1, 16, T, H, W, generator=torch.Generator().manual_seed(3))
+    ref = VO.vae_decode(P, cfg, z.to(H16).float())
+    got = vae_decode(z.to(DEV), vae)
+    assert tuple(got.shape) == (1, 3, 4 * (T - 1) + 1, 8 * H, 8 * W) and got.dtype == H16
+    assert psnr(got, ref) >= 40.0, psnr(got, ref)
+    assert rel_l2(got, ref) < 1e-2
+
+
+def test_framewise_decode_windows_and_crossfade_match_oracle():
+    cfg, P, vae = build(SMALL, seed=1)
+    z = torch.randn(1, 16, 9, 6, 6, generator=torch.Generator().manual_seed(4))     # 9 latent frames: windows at 0,3,6
+    ref = VO.vae_decode(P, cfg, z.to(H16).float())
+    got = vae_decode(z.to(DEV), vae)
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 3, 33, 48, 48)
+    assert psnr(got, ref) >= 40.0, psnr(got, ref)
+    vae.use_framewise_decoding = False
+    whole = vae_decode(z.to(DEV), vae)
+    assert psnr(whole, VO.vae_decode(P, cfg, z.to(H16).float(), framewise=False)) >= 40.0
+
+
+def test_image_mode_decodes_frames_independently():
+    cfg, P, vae = build(SMALL, seed=2)
+    z = torch.randn(1, 16, 2, 6, 6, generator=torch.Generator().manual_seed(5))
+    got = vae_decode(z.to(DEV), vae, image_mode=True)
+    ref = torch.cat([VO.vae_decode(P, cfg, z[:, :, i:i + 1].to(H16).float()) for i in range(2)], dim=2)
+    assert tuple(got.shape) == (1, 3, 2, 48, 48) and psnr(got, ref) >= 40.0
