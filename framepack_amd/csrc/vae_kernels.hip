@@ -90,23 +90,31 @@ __global__ __launch_bounds__(GN_THREADS) void gn_partial_kernel(const f16* __res
     }
 }
 
-// Stage 2: stats[g] = (mean, rstd) of group g (C / groups channels), partials summed in block order.
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C, int groups, int64_t rows,
-                                   float eps, float* __restrict__ stats) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= groups) return;
+// Stage 2: stats[g] = (mean, rstd) of group g (C / groups channels).  One wave per group: lane l sums the
+// partials of blocks l, l+64, ... in order, then the lanes are combined by a fixed butterfly: deterministic.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nblocks, int C,
+                                                         int groups, int64_t rows, float eps,
+                                                         float* __restrict__ stats) {
+    const int g = blockIdx.x, lane = threadIdx.x;
     const int quads = (C / groups) >> 2;             // 4-channel quads per group
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b)
+    for (int b = lane; b < nblocks; b += 64)
         for (int i = 0; i < quads; ++i) {
             const float* p = partial + ((int64_t)b * (C >> 2) + g * quads + i) * 2;
             s += p[0]; q += p[1];
         }
-    const double n = (double)rows * (C / groups);
-    const double mean = s / n;
-    const double var = fmax(q / n - mean * mean, 0.0);
-    stats[2 * g] = (float)mean;
-    stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) {
+        const double n = (double)rows * (C / groups);
+        const double mean = s / n;
+        const double var = fmax(q / n - mean * mean, 0.0);
+        stats[2 * g] = (float)mean;
+        stats[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // y = f((x - mean_g) * rstd_g * gamma_c + beta_c),  f = SiLU or identity
@@ -198,7 +206,7 @@ extern "C" int fp_groupnorm_stats_f16(const void* x, int64_t rows, int C, int gr
     hipStream_t st = (hipStream_t)stream;
     gn_partial_kernel<<<dim3(nblocks), dim3(GN_THREADS), 0, st>>>((const f16*)x, rows, C, workspace);
     FP_CHECK_LAUNCH();
-    gn_finalize_kernel<<<dim3((groups + 63) / 64), dim3(64), 0, st>>>(workspace, nblocks, C, groups, rows, eps, stats);
+    gn_finalize_kernel<<<dim3(groups), dim3(64), 0, st>>>(workspace, nblocks, C, groups, rows, eps, stats);
     FP_CHECK_LAUNCH();
     return 0;
 }
