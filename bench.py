@@ -18,6 +18,8 @@ Also printed on the same JSON line:
   roofline     - the dominant kernel (K1 flash attention): algorithmic FLOPs per launch (4 * S^2 * heads * 128,
                  per rank) / its average duration measured live with events on its own stream over the timed
                  region, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  vae_decode   - (N == 1, informational; not part of `value`) the causal-3D VAE decode of the section's 9 latent
+                 frames to 33 frames at 640x640 (framepack_amd/vae.py, random-init fp16 weights), ms per decode.
   cpu_baseline - the CPU oracle (kind "port") timed on this box's host cores on a bounded sample
                  (rank 0, N == 1 only): one double-stream + one single-stream block at full width and full S,
                  extrapolated x20 / x40 / x25 to a section (labelled as such).
@@ -81,6 +83,27 @@ def cpu_baseline(S_img, S_txt, threads):
             "kind": "port",
             "sample": f"1 double block ({td:.1f} s) + 1 single block ({ts:.1f} s) of the fp32 CPU oracle at full width "
                       f"(d=3072, 24 heads) and full S={S_img + S_txt}; section = (20*double + 40*single)*25, extrapolated"}
+
+
+def vae_decode_ms(dev, t_lat, h_lat, w_lat):
+    """One section's VAE decode (ref: diffusers_helper/hunyuan.py:93-103) on the HIP decoder, events on the stream."""
+    from framepack_amd.vae import AutoencoderKLHunyuanVideo, vae_decode
+    torch.manual_seed(0)
+    vae = AutoencoderKLHunyuanVideo()
+    for p in vae.parameters():
+        if p.dim() > 1:
+            torch.nn.init.normal_(p, std=p[0].numel() ** -0.5)
+    vae = vae.to(dev, torch.float16).eval()
+    z = torch.randn(1, 16, t_lat, h_lat, w_lat, device=dev)
+    out = vae_decode(z, vae)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(2):
+        out = vae_decode(z, vae)
+    b.record()
+    torch.cuda.synchronize()
+    return {"ms": round(a.elapsed_time(b) / 2, 1), "latent": [1, 16, t_lat, h_lat, w_lat], "frames": list(out.shape),
+            "dtype": "f16", "note": "framewise windows of 4+1 latent frames, as diffusers' default"}
 
 
 def main():
@@ -166,7 +189,7 @@ def main():
     att_avg_s = sum(att_ms) / len(att_ms) / 1e3
     flops_per_launch = 4.0 * rows * rows * heads * 128
     achieved = flops_per_launch / att_avg_s
-    roofline = {"kernel": "attn_fwd_kernel (K1 flash attention, bf16 MFMA 32x32x16)", "bound": "mfma",
+    roofline = {"kernel": "attn_fwd_kernel<8> (K1 flash attention, bf16 MFMA 32x32x16, ping-pong schedule)", "bound": "mfma",
                 "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_PEAK, 4), "traffic": None,
                 "launches": len(att_ms), "avg_launch_ms": round(att_avg_s * 1e3, 4),
@@ -189,6 +212,8 @@ def main():
         if args.config == "13b":
             fl = (24 * 3072 ** 2 * S + 4 * S * S * 3072) * 60
             line["model_mfma_frac"] = round(fl / (ms_per_step / 1e3) / (MFMA_BF16_PEAK * world), 4)
+        if world == 1 and args.config == "13b":
+            line["vae_decode"] = vae_decode_ms(dev, frames_latent, height // 8, width // 8)
         if world == 1 and not args.no_cpu_baseline and args.config == "13b":
             line["cpu_baseline"] = cpu_baseline(Si, St, args.cpu_threads)
         print(json.dumps(line), flush=True)

@@ -289,6 +289,58 @@ class AutoencoderKLHunyuanVideo(nn.Module):
             b[:, :, x] = a[:, :, -extent + x] * (1 - x / extent) + b[:, :, x] * (x / extent)
         return b
 
+    def enable_window_parallel(self, group=None) -> None:
+        """Multi-GPU decode (new design; the reference is single-GPU): the framewise windows are independent
+        given the replicated latents (each window re-reads its 4+1 latent frames, the causal convolutions need
+        nothing to the left of the window's first frame by construction of diffusers' windows), so window n is
+        decoded by rank n % P and broadcast; every rank then does the same cross-fade.  Results are identical to
+        the single-GPU framewise decode."""
+        import torch.distributed as dist
+        self._wp_group = group if group is not None else dist.group.WORLD
+
+    def _framewise(self, z: torch.Tensor, tile_fn) -> torch.Tensor:
+        """diffusers' _temporal_tiled_decode: windows of t_min+1 latent frames at stride t_stride, the first
+        decoded frame of every later window dropped, consecutive windows cross-faded over `blend` frames."""
+        tr = self.config.temporal_compression_ratio
+        T = z.shape[2]
+        t_min, t_stride = self.tile_sample_min_num_frames // tr, self.tile_sample_stride_num_frames // tr
+        starts = list(range(0, T, t_stride))
+        group = getattr(self, "_wp_group", None)
+        rows = []
+        if group is None:
+            for i in starts:
+                d = tile_fn(z[:, :, i:i + t_min + 1])
+                rows.append(d[:, :, 1:] if i > 0 else d)
+        else:
+            import torch.distributed as dist
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            sr = self.config.spatial_compression_ratio
+            mine = {n: tile_fn(z[:, :, i:i + t_min + 1]) for n, i in enumerate(starts) if n % world == rank}
+            like = next(iter(mine.values())) if mine else None
+            for n, i in enumerate(starts):
+                n_lat = min(t_min + 1, T - i)
+                shape = (1, self.config.out_channels, (n_lat - 1) * tr + 1, z.shape[3] * sr, z.shape[4] * sr)
+                if n % world == rank:
+                    d = mine[n].contiguous()
+                    assert tuple(d.shape) == shape
+                else:
+                    d = torch.empty(shape, dtype=like.dtype if like is not None else self._wp_dtype(z),
+                                    device=z.device)
+                dist.broadcast(d, src=dist.get_global_rank(group, n % world), group=group)
+                rows.append(d[:, :, 1:] if i > 0 else d)
+        blend = self.tile_sample_min_num_frames - self.tile_sample_stride_num_frames
+        out = []
+        for n, tile in enumerate(rows):
+            if n > 0:
+                tile = self._blend_t(rows[n - 1], tile, blend)
+                out.append(tile[:, :, :self.tile_sample_stride_num_frames])
+            else:
+                out.append(tile[:, :, :self.tile_sample_stride_num_frames + 1])
+        return torch.cat(out, dim=2)[:, :, :(T - 1) * tr + 1]
+
+    def _wp_dtype(self, z: torch.Tensor) -> torch.dtype:
+        return F16 if z.is_cuda else z.dtype
+
     @torch.no_grad()
     def decode(self, z: torch.Tensor, return_dict: bool = True):
         """`vae.decode(latents).sample`.  More than 4 latent frames are decoded in windows of 4+1 latent frames
@@ -297,25 +349,11 @@ class AutoencoderKLHunyuanVideo(nn.Module):
             raise RuntimeError("framepack_amd VAE decode runs on the GPU only; there is no CPU fallback")
         if z.dim() != 5 or z.shape[0] != 1:
             raise ValueError(f"expected latents [1, C, T, H, W], got {tuple(z.shape)}")
-        tr = self.config.temporal_compression_ratio
-        T = z.shape[2]
-        t_min, t_stride = self.tile_sample_min_num_frames // tr, self.tile_sample_stride_num_frames // tr
-        if not self.use_framewise_decoding or T <= t_min:
+        t_min = self.tile_sample_min_num_frames // self.config.temporal_compression_ratio
+        if not self.use_framewise_decoding or z.shape[2] <= t_min:
             dec = self._decode_tile(z)
         else:
-            rows = []
-            for i in range(0, T, t_stride):
-                d = self._decode_tile(z[:, :, i:i + t_min + 1])
-                rows.append(d[:, :, 1:] if i > 0 else d)
-            blend = self.tile_sample_min_num_frames - self.tile_sample_stride_num_frames
-            out = []
-            for i, tile in enumerate(rows):
-                if i > 0:
-                    tile = self._blend_t(rows[i - 1], tile, blend)
-                    out.append(tile[:, :, :self.tile_sample_stride_num_frames])
-                else:
-                    out.append(tile[:, :, :self.tile_sample_stride_num_frames + 1])
-            dec = torch.cat(out, dim=2)[:, :, :(T - 1) * tr + 1]
+            dec = self._framewise(z, self._decode_tile)
         dec = dec.to(self.dtype) if dec.dtype != self.dtype else dec
         return DecoderOutput(sample=dec) if return_dict else (dec,)
 
