@@ -22,6 +22,7 @@ namespace {
 constexpr int KVBLK = 64;     // keys per tile
 constexpr int HD = 128;       // head dim
 constexpr int KBUF = KVBLK * HD * 2;   // 16 KiB per K (or V) buffer
+constexpr int WS_FLOATS = 256 * HD + 2 * 256;   // one partial sweep: O[256][128], m[256], l[256] (fp32)
 
 __device__ __forceinline__ unsigned k_lds_off(int key, int chunk) {      // chunk = 16-B piece of the 256-B row
     return (unsigned)(key * 256 + ((chunk ^ (key & 15)) << 4));
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
                                                              const bf16* __restrict__ V, bf16* __restrict__ O,
                                                              int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
                                                              const int* __restrict__ cu_seqlens, int nseg, int total,
-                                                             int heads, int nqb, float scale_log2e) {
+                                                             int heads, int nqb, float scale_log2e, int nwg_full,
+                                                             int split, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* kbuf = smem;                 // [2][KBUF]
     unsigned char* vbuf = smem + 2 * KBUF;      // [2][KBUF]
@@ -79,7 +81,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     const int grp = wave >> 2;
     const int r = lane & 31, hh = lane >> 5;
 
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    // Work items [0, nwg_full) are whole (head, q block) sweeps, dealt so that consecutive items of one XCD share
+    // a head (K/V through its L2).  The items of the last, partial round are each cut into `split` KV ranges
+    // (blocks >= nwg_full) that write partial (O, m, l) to `ws` for attn_combine_kernel: the chip stays full.
+    int w, part = 0, nparts = 1;
+    if ((int)blockIdx.x < nwg_full) {
+        w = xcd_remap(blockIdx.x, nwg_full);
+    } else {
+        const int si = blockIdx.x - nwg_full;
+        w = nwg_full + si / split;
+        part = si % split;
+        nparts = split;
+    }
     const int qb = w % nqb;
     const int head = (w / nqb) % heads;
     const int seg = w / (nqb * heads);
@@ -91,7 +104,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     const int q0 = seg_lo + qb * QBLK;
     if (q0 >= seg_hi) return;                   // uniform for the workgroup
     const int nkv = seg_hi - seg_lo;
-    const int nt = (nkv + KVBLK - 1) / KVBLK;
+    const int nt_all = (nkv + KVBLK - 1) / KVBLK;
+    const int t0 = (int)((int64_t)nt_all * part / nparts);          // this block's KV tiles: [t0, t0 + nt)
+    const int nt = (int)((int64_t)nt_all * (part + 1) / nparts) - t0;
+    float* wsp = ws + (int64_t)((w - nwg_full) * split + part) * WS_FLOATS;
+    if (nt == 0) {                              // (uniform) more parts than tiles: a neutral partial
+        for (int i = tid; i < 256; i += 512) {
+            wsp[256 * HD + i] = -INFINITY;
+            wsp[256 * HD + 256 + i] = 0.f;
+        }
+        return;
+    }
 
     const int qrow = min(q0 + wave * 32 + r, seg_hi - 1);
     bf16x8 qf[8];
@@ -111,8 +134,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     unsigned k_cur[2], v_cur[2];                // byte offsets of this thread's two rows in the NEXT tile to load
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        k_cur[i] = (unsigned)((seg_lo + sk0 + 32 * i) * k_rs * 2) + col_b;
-        v_cur[i] = (unsigned)((seg_lo + sk0 + 32 * i) * v_rs * 2) + col_b;
+        k_cur[i] = (unsigned)((seg_lo + t0 * KVBLK + sk0 + 32 * i) * k_rs * 2) + col_b;
+        v_cur[i] = (unsigned)((seg_lo + t0 * KVBLK + sk0 + 32 * i) * v_rs * 2) + col_b;
     }
     u32x4 kreg[2], vreg[2];
     auto load_k = [&]() {
@@ -188,8 +211,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
         load_k();                               // K(t+2)
         load_v();                               // V(t+1)
 
-        if (t == nt - 1 && (nkv & (KVBLK - 1))) {
-            const int valid = nkv - t * KVBLK;
+        if (t0 + t == nt_all - 1 && (nkv & (KVBLK - 1))) {
+            const int valid = nkv - (t0 + t) * KVBLK;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -320,6 +343,24 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
     const float l_tot = l_run + other_half(l_run);
+    if (nparts > 1) {                           // partial sweep: unnormalised O (fp32), running max and sum
+        const int row = wave * 32 + r;
+        float* op = wsp + row * HD + 4 * hh;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o_acc[d][4 * g + j];
+                *reinterpret_cast<f32x4*>(op + d * 32 + g * 8) = v;
+            }
+        if (hh == 0) {
+            wsp[256 * HD + row] = m_run;
+            wsp[256 * HD + 256 + row] = l_tot;
+        }
+        return;
+    }
     const float inv = 1.f / l_tot;
     const int qrow_real = q0 + wave * 32 + r;
     if (qrow_real < seg_hi) {
@@ -336,7 +377,65 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     }
 }
 
+// Merge the `split` partial sweeps of each tail item: O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).
+// One workgroup = 16 query rows x 16 chunks of 8 head-dim columns.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, bf16* __restrict__ O,
+                                                           int64_t o_rs, const int* __restrict__ cu_seqlens, int total,
+                                                           int heads, int nqb, int nwg_full, int split) {
+    const int item = nwg_full + blockIdx.x / 16;
+    const int row = (blockIdx.x % 16) * 16 + (threadIdx.x >> 4), c8 = (threadIdx.x & 15) * 8;
+    const int qb = item % nqb, head = (item / nqb) % heads, seg = item / (nqb * heads);
+    int seg_lo = 0, seg_hi = total;
+    if (cu_seqlens) {
+        seg_lo = cu_seqlens[seg];
+        seg_hi = cu_seqlens[seg + 1];
+    }
+    const int q = seg_lo + qb * 256 + row;
+    if (q >= seg_hi) return;
+    const float* base = ws + (int64_t)(blockIdx.x / 16) * split * WS_FLOATS;
+    float M = -INFINITY;
+    for (int i = 0; i < split; ++i) M = fmaxf(M, base[i * WS_FLOATS + 256 * HD + row]);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, L = 0.f;
+    for (int i = 0; i < split; ++i) {
+        const float* p = base + i * WS_FLOATS;
+        const float m = p[256 * HD + row];
+        if (m == -INFINITY) continue;
+        const float f = __builtin_amdgcn_exp2f(m - M);
+        L += p[256 * HD + 256 + row] * f;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + row * HD + c8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p + row * HD + c8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] += a[j] * f;
+            acc[4 + j] += b[j] * f;
+        }
+    }
+    const float inv = 1.f / L;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(acc[j] * inv);
+    bf16* op = O + (int64_t)q * o_rs + head * HD + c8;
+    *reinterpret_cast<bf16x4*>(op) = bf16x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<bf16x4*>(op + 4) = bf16x4{o[4], o[5], o[6], o[7]};
+}
+
+int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 }  // namespace
+
+// Bytes of device workspace with which fp_attn_fwd_bf16 can split the last round's work items (any shape).
+extern "C" int64_t fp_attn_workspace_bytes(void) { return (int64_t)cu_count() * WS_FLOATS * 4; }
 
 // q, k, v, o: bf16 [total_tokens, heads, 128] with arbitrary row strides (elements) and head stride 128.
 // cu_seqlens: device int32 [nseg+1] or NULL for a single segment [0, total_tokens).
@@ -344,7 +443,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
 extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
                                 int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
                                 const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens, int heads,
-                                int head_dim, float softmax_scale, void* stream) {
+                                int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
     FP_REQUIRE(q && k && v && o && head_dim == HD && heads > 0 && total_tokens >= 0 && nseg >= 1);
     FP_REQUIRE(max_seqlen >= 0 && max_seqlen <= total_tokens);
     FP_REQUIRE(q_row_stride % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && o_row_stride % 4 == 0);
@@ -361,14 +461,32 @@ extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     const int nqb = (max_seqlen + 255) / 256;
     const int64_t nwg = (int64_t)nqb * heads * nseg;
     FP_REQUIRE(nwg < (1ll << 31));
+    // One workgroup per CU is resident (8 waves x 238 registers): nwg items take ceil(nwg / CUs) rounds.  When the
+    // last round is at most half full and the caller gave a workspace, its items are each cut into `split` KV
+    // ranges so that the round takes 1 / split of a sweep (+ a small merge) instead of a whole one.
+    const int ncu = cu_count();
+    int nwg_full = (int)nwg, split = 1;
+    const int tail = (int)(nwg % ncu);
+    if (workspace && nwg > ncu && tail > 0 && tail <= ncu / 2) {
+        split = ncu / tail < 8 ? ncu / tail : 8;
+        if ((int64_t)tail * split * WS_FLOATS * 4 <= workspace_bytes && ((uintptr_t)workspace & 15) == 0)
+            nwg_full = (int)nwg - tail;
+        else
+            split = 1;
+    }
+    const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
     // defer-max threshold 2^8: P <= 256 before the bf16 rounding (relative precision unchanged), the O rescale
     // runs only when a row's max grows by more than 8 in the log2 domain
     auto kern = attn_fwd_kernel<8>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KBUF);
     if (e != hipSuccess) return (int)e;
-    kern<<<dim3((unsigned)nwg), dim3(512), 4 * KBUF, (hipStream_t)stream>>>(
+    kern<<<dim3((unsigned)grid), dim3(512), 4 * KBUF, (hipStream_t)stream>>>(
         (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
-        o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e);
+        o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
+    FP_CHECK_LAUNCH();
+    if (nwg_full < nwg)
+        attn_combine_kernel<<<dim3((unsigned)((nwg - nwg_full) * 16)), dim3(256), 0, (hipStream_t)stream>>>(
+            (const float*)workspace, (bf16*)o, o_row_stride, cu_seqlens, total_tokens, heads, nqb, nwg_full, split);
     FP_CHECK_LAUNCH();
     return 0;
 }

@@ -17,7 +17,8 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 # name -> argtypes, exactly the declarations of include/framepack_hip.h
 SIGNATURES = {
     "fp_abi_version": [],
-    "fp_attn_fwd_bf16": [P, P, P, P, L, L, L, L, P, I, I, I, I, I, F, P],
+    "fp_attn_workspace_bytes": [],
+    "fp_attn_fwd_bf16": [P, P, P, P, L, L, L, L, P, I, I, I, I, I, F, P, L, P],
     "fp_qk_rmsnorm_rope_bf16": [P, P, L, I, I, I, P, P, P, P, P, I, F, P],
     "fp_layernorm_modulate_bf16": [P, L, P, P, P, L, I, I, F, P],
     "fp_gate_residual_bf16": [P, L, P, L, P, I, I, P],
@@ -52,7 +53,7 @@ def load() -> ctypes.CDLL:
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name.endswith("_bytes") else c_int
     _lib = lib
     return lib
 

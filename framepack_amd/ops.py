@@ -95,6 +95,19 @@ def qk_rmsnorm_rope_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: tor
                "fp_qk_rmsnorm_rope_bf16")
 
 
+_ATTN_WS = {}
+
+
+def _attn_workspace(device: torch.device) -> torch.Tensor:
+    """Per-device scratch for the attention kernel's split last round (allocated once, by the caller: the
+    library itself allocates nothing).  Calls on one device share it, so they must be stream-ordered."""
+    ws = _ATTN_WS.get(device)
+    if ws is None:
+        ws = torch.empty((_lib.load().fp_attn_workspace_bytes(),), dtype=torch.uint8, device=device)
+        _ATTN_WS[device] = ws
+    return ws
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
               cu_seqlens: Optional[torch.Tensor] = None, max_seqlen: Optional[int] = None,
               scale: Optional[float] = None) -> torch.Tensor:
@@ -122,8 +135,10 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
     if ATTN_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(q.device))
+    ws = _attn_workspace(q.device)
     _lib.check(_lib.load().fp_attn_fwd_bf16(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o2.data_ptr(), qs, ks, vs, os_,
-                                            _ptr(cu_seqlens), nseg, max_seqlen, rows, heads, 128, scale, _stream(q)),
+                                            _ptr(cu_seqlens), nseg, max_seqlen, rows, heads, 128, scale,
+                                            ws.data_ptr(), ws.numel(), _stream(q)),
                "fp_attn_fwd_bf16")
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(q.device))

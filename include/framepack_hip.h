@@ -32,11 +32,17 @@ int fp_abi_version(void);
  * SDPA branch :97).  q,k,v,o: [total_tokens, heads, 128]; segment s covers token rows
  * cu_seqlens[s] .. cu_seqlens[s+1] (int32, device; the layout :63-77 builds), or pass NULL with nseg = 1
  * for one segment over all rows (the B == 1 branch :927-932).  max_seqlen >= the longest segment.
- * `o` may alias `q`.  o needs 8-byte alignment / stride % 4 only. */
+ * `o` may alias `q`.  o needs 8-byte alignment / stride % 4 only.  K and V must each span < 4 GiB.
+ * workspace (optional, may be NULL): fp_attn_workspace_bytes() bytes of device memory, 16-byte aligned.  With
+ * it, when the work items (heads x 256-row query blocks) do not fill the last round of the chip, that round's
+ * items are swept in parallel KV ranges and merged (same result to fp32 rounding); without it the call is
+ * unchanged but the last round runs partly idle.  The library allocates nothing either way. */
+int64_t fp_attn_workspace_bytes(void);
 int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o,
                      int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
                      const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens,
-                     int heads, int head_dim, float softmax_scale, void* stream);
+                     int heads, int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                     void* stream);
 
 /* K2  in-place RMSNorm over head_dim (=128) of q and k, then RoPE on token rows [0, rope_rows).
  * Replaces diffusers_helper/dit_common.py:31-39 (RMSNorm_forward) + hunyuan_video_packed.py:80-86

@@ -102,12 +102,12 @@ def test_cu_seqlens_layout():
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "framepack_hip.h")).read()
-    declared = set(re.findall(r"^int\s+(fp_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t)\s+(fp_\w+)\s*\(", header, flags=re.M))
     assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().fp_abi_version() == 1
+    assert lib.load().fp_abi_version() == 2
 
 
 def test_forward_refuses_cpu_tensors(tiny_model):

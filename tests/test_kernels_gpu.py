@@ -237,3 +237,18 @@ def test_attention_full_size_properties():
         qh, kh, vh = q[rows][:, sl].cpu().double(), k[:, sl].cpu().double(), v[:, sl].cpu().double()
         p = torch.softmax(qh @ kh.T / math.sqrt(128.0), dim=-1)
         assert rel_l2(o[rows][:, sl], p @ vh) < 6e-3
+
+
+def test_attention_split_last_round_matches_unsplit_sweeps():
+    """261 work items on a 256-CU chip: the 5 items of the last round are swept as 8 KV ranges each and merged
+    (fp_attn_fwd_bf16 with a workspace).  Their rows, and rows of unsplit items, against an fp32 reference; the
+    ragged last query block and last KV tile are inside the split items."""
+    S, heads = 86 * 256 + 10, 3
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q, k, v = (torch.randn(S, heads * 128, generator=g, device=DEV).to(BF) for _ in range(3))
+    o = ops.attention(q, k, v, heads)
+    assert torch.isfinite(o.float()).all()
+    for h, lo, hi in ((2, 82 * 256, S), (2, 0, 300), (0, 21000, S), (1, 11000, 11300)):
+        sl = slice(h * 128, (h + 1) * 128)
+        p = torch.softmax(q[lo:hi, sl].float() @ k[:, sl].float().T / math.sqrt(128.0), dim=-1)
+        assert rel_l2(o[lo:hi, sl], p @ v[:, sl].float()) < 5e-3, (h, lo)
