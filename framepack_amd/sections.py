@@ -1,0 +1,113 @@
+"""Headless section driver: the reference worker's generation loop without the Gradio plumbing.
+
+Mirrors ref: framepack/worker.py:325-350 (history buffer, latent-padding schedule), :430-465 (end-frame latent,
+index split), :503-505 (clean latents from the history), :621-664 (sampling call, start-latent prepend, history
+update), :703-720 (which latent frames are decoded and how they are cross-faded) and
+ref: diffusers_helper/utils.py:64-75 (soft_append_bcthw).  It is pure tensor bookkeeping with exact integer
+semantics; the two heavy calls are injected (`sample_fn` = framepack_amd.sampler.sample_hunyuan over the HIP DiT,
+`decode_fn` = framepack_amd.vae.vae_decode over the HIP VAE), so the same loop runs on ranks without a UI
+(sequence-parallel DiT, window-parallel VAE) and in the CPU tests with stand-ins.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+
+def latent_paddings(total_latent_sections: int, one_frame_inference: bool = False) -> List[int]:
+    """ref worker.py:337-350.  Sections are generated from the END of the video to its start; the padding is
+    the number of latent windows left between the start frame and the section."""
+    total_latent_sections = int(max(total_latent_sections, 1))                 # ref :95
+    if one_frame_inference:
+        return [0]
+    if total_latent_sections > 4:
+        return [3] + [2] * (total_latent_sections - 3) + [1, 0]
+    return list(reversed(range(total_latent_sections)))
+
+
+def section_indices(latent_padding: int, latent_window_size: int, one_frame_inference: bool = False) -> Dict[str, Optional[torch.Tensor]]:
+    """ref worker.py:463-481: frame positions [start | padding | window | 1 post | 2 (2x) | 16 (4x)]."""
+    pad = latent_padding * latent_window_size
+    idx = torch.arange(0, sum([1, pad, latent_window_size, 1, 2, 16])).unsqueeze(0)
+    pre, _, latent, post, two, four = idx.split([1, pad, latent_window_size, 1, 2, 16], dim=1)
+    out = dict(latent_indices=latent, clean_latent_indices=torch.cat([pre, post], dim=1),
+               clean_latent_2x_indices=two, clean_latent_4x_indices=four)
+    if one_frame_inference:
+        out["latent_indices"] = latent[:, -1:]
+        out["clean_latent_2x_indices"] = None
+        out["clean_latent_4x_indices"] = None
+    return out
+
+
+def soft_append_bcthw(history: torch.Tensor, current: torch.Tensor, overlap: int = 0) -> torch.Tensor:
+    """ref diffusers_helper/utils.py:64-75: linear cross-fade of `overlap` frames between two clips."""
+    if overlap <= 0:
+        return torch.cat([history, current], dim=2)
+    assert history.shape[2] >= overlap, f"History length ({history.shape[2]}) must be >= overlap ({overlap})"
+    assert current.shape[2] >= overlap, f"Current length ({current.shape[2]}) must be >= overlap ({overlap})"
+    weights = torch.linspace(1, 0, overlap, dtype=history.dtype, device=history.device).view(1, 1, -1, 1, 1)
+    blended = weights * history[:, :, -overlap:] + (1 - weights) * current[:, :, :overlap]
+    return torch.cat([history[:, :, :-overlap], blended, current[:, :, overlap:]], dim=2).to(history)
+
+
+@dataclass
+class SectionResult:
+    history_latents: torch.Tensor              # [1, 16, generated + 19, h, w] fp32 (CPU), newest section first
+    history_pixels: Optional[torch.Tensor]     # [1, 3, frames, H, W]
+    total_generated_latent_frames: int
+    sections: List[dict] = field(default_factory=list)
+
+
+@torch.no_grad()
+def generate_sections(sample_fn: Callable, decode_fn: Optional[Callable], start_latent: torch.Tensor, height: int,
+                      width: int, total_latent_sections: int, latent_window_size: int = 9, seed: int = 31337,
+                      end_latent: Optional[torch.Tensor] = None, end_frame_strength: float = 1.0,
+                      one_frame_inference: bool = False, section_latents: Optional[Dict[int, torch.Tensor]] = None,
+                      sample_kwargs: Optional[dict] = None, on_section: Optional[Callable] = None) -> SectionResult:
+    """The reference's section loop (ref worker.py:325-332, 430-720).
+
+    sample_fn(frames=..., generator=..., latent_indices=..., clean_latents=..., ... , **sample_kwargs)
+        -> generated latents [1, 16, T, h, w]            (sample_hunyuan's contract)
+    decode_fn(latents) -> pixels [1, 3, 4(T-1)+1, 8h, 8w] (vae_decode's contract), or None to skip decoding
+    section_latents: optional per-section replacement of the start latent (ref get_section_latent)."""
+    rnd = torch.Generator("cpu").manual_seed(seed)
+    num_frames = latent_window_size * 4 - 3
+    history_latents = torch.zeros((1, 16, 1 + 2 + 16, height // 8, width // 8), dtype=torch.float32)
+    history_pixels = None
+    total = 0
+    log: List[dict] = []
+    paddings = latent_paddings(total_latent_sections, one_frame_inference)
+    for i_section, latent_padding in enumerate(paddings):
+        is_first, is_last = i_section == 0, latent_padding == 0
+        if is_first and end_latent is not None:                                   # ref :450-459
+            history_latents[:, :, 0:1] = end_latent * end_frame_strength if end_frame_strength != 1.0 else end_latent
+        idx = section_indices(latent_padding, latent_window_size, one_frame_inference)
+        current = start_latent if not section_latents or i_section not in section_latents else section_latents[i_section]
+        clean_pre = current.to(history_latents)
+        clean_post, clean_2x, clean_4x = history_latents[:, :, :1 + 2 + 16].split([1, 2, 16], dim=2)
+        kw = dict(clean_latents=torch.cat([clean_pre, clean_post], dim=2), clean_latents_2x=clean_2x,
+                  clean_latents_4x=clean_4x, **idx)
+        frames = num_frames
+        if one_frame_inference:                                                   # ref :468-481
+            kw["clean_latents_2x"] = kw["clean_latents_4x"] = None
+            frames = 1
+        generated = sample_fn(width=width, height=height, frames=frames, generator=rnd, **kw, **(sample_kwargs or {}))
+        if is_last and not one_frame_inference:                                   # ref :655-656
+            generated = torch.cat([start_latent.to(generated), generated], dim=2)
+        total += int(generated.shape[2])
+        history_latents = torch.cat([generated.to(history_latents), history_latents], dim=2)
+        real = history_latents[:, :, :total]
+        if decode_fn is not None:                                                 # ref :710-720
+            if history_pixels is None:
+                history_pixels = decode_fn(real).cpu()
+            else:
+                n_lat = (latent_window_size * 2 + 1) if is_last else (latent_window_size * 2)
+                history_pixels = soft_append_bcthw(decode_fn(real[:, :, :n_lat]).cpu(), history_pixels,
+                                                   latent_window_size * 4 - 3)
+        log.append(dict(section=i_section, latent_padding=latent_padding, is_last=is_last, total_latent_frames=total,
+                        pixel_frames=None if history_pixels is None else int(history_pixels.shape[2])))
+        if on_section is not None:
+            on_section(log[-1], history_pixels)
+    return SectionResult(history_latents, history_pixels, total, log)

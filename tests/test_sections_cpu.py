@@ -1,0 +1,94 @@
+"""Section driver (framepack_amd/sections.py) against the oracle's restatement and the values the reference
+documents: padding schedule, index layout, history update, decode windows and cross-fade.  The sampler and the
+VAE are stand-ins with the right contracts (T latent frames -> 4(T-1)+1 frames), so only the bookkeeping is
+under test here; the real kernels are covered by the GPU tests."""
+import numpy as np
+import pytest
+import torch
+
+from framepack_amd import sections as S
+from oracle import sections_oracle as SO
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 9])
+def test_latent_padding_schedule(n):
+    assert S.latent_paddings(n) == SO.paddings(n)
+    assert S.latent_paddings(n)[-1] == 0
+    assert S.latent_paddings(n, one_frame_inference=True) == [0]
+    assert S.latent_paddings(5) == [3, 2, 2, 1, 0] and S.latent_paddings(3) == [2, 1, 0] and S.latent_paddings(0) == [0]
+
+
+@pytest.mark.parametrize("pad,window", [(0, 9), (1, 9), (3, 9), (2, 5), (0, 33)])
+def test_section_indices_layout(pad, window):
+    got, want = S.section_indices(pad, window), SO.indices(pad, window)
+    assert got["latent_indices"][0].tolist() == want["latent"].tolist()
+    assert got["clean_latent_indices"][0].tolist() == want["clean"].tolist()
+    assert got["clean_latent_2x_indices"][0].tolist() == want["two"].tolist()
+    assert got["clean_latent_4x_indices"][0].tolist() == want["four"].tolist()
+    assert got["latent_indices"].dtype == torch.int64
+    if (pad, window) == (0, 9):        # the last section at window 9 (from ref worker.py:463-465)
+        assert got["latent_indices"][0].tolist() == list(range(1, 10))
+        assert got["clean_latent_indices"][0].tolist() == [0, 10]
+        assert got["clean_latent_2x_indices"][0].tolist() == [11, 12]
+        assert got["clean_latent_4x_indices"][0].tolist() == list(range(13, 29))
+    one = S.section_indices(pad, window, one_frame_inference=True)
+    assert one["latent_indices"][0].tolist() == [want["latent"][-1]] and one["clean_latent_2x_indices"] is None
+
+
+@pytest.mark.parametrize("overlap", [0, 1, 5, 33])
+def test_soft_append_matches_oracle(overlap):
+    g = torch.Generator().manual_seed(overlap)
+    h, c = torch.randn(1, 3, 40, 4, 4, generator=g), torch.randn(1, 3, 37, 4, 4, generator=g)
+    got = S.soft_append_bcthw(h, c, overlap)
+    want = SO.crossfade(h[0].permute(1, 0, 2, 3).numpy(), c[0].permute(1, 0, 2, 3).numpy(), overlap)
+    np.testing.assert_allclose(got[0].permute(1, 0, 2, 3).numpy(), want, rtol=1e-6, atol=1e-6)
+    assert got.shape[2] == 40 + 37 - overlap
+    with pytest.raises(AssertionError):
+        S.soft_append_bcthw(h[:, :, :2], c, 5)
+
+
+def _stubs(calls):
+    def sample_fn(width, height, frames, generator, latent_indices, clean_latents, clean_latent_indices,
+                  clean_latents_2x, clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices, **kw):
+        T = (frames + 3) // 4
+        calls.append(dict(T=T, latent_indices=latent_indices[0].tolist(), clean=clean_latents.clone(),
+                          two=None if clean_latents_2x is None else clean_latents_2x.clone(),
+                          four=None if clean_latents_4x is None else clean_latents_4x.clone()))
+        return torch.full((1, 16, T, height // 8, width // 8), float(len(calls)))
+
+    def decode_fn(lat):
+        T = lat.shape[2]
+        px = lat[:, :3].repeat_interleave(4, dim=2)[:, :, 3:]               # 4(T-1)+1 frames, value = latent value
+        return px.repeat_interleave(8, dim=3).repeat_interleave(8, dim=4)
+    return sample_fn, decode_fn
+
+
+@pytest.mark.parametrize("n_sections,window", [(1, 9), (3, 9), (5, 4)])
+def test_generate_sections_history_and_decode_windows(n_sections, window):
+    calls = []
+    sample_fn, decode_fn = _stubs(calls)
+    start = torch.full((1, 16, 1, 4, 4), -1.0)
+    end = torch.full((1, 16, 1, 4, 4), 7.0)
+    res = S.generate_sections(sample_fn, decode_fn, start, 32, 32, n_sections, latent_window_size=window,
+                              end_latent=end, end_frame_strength=0.5)
+    counts = SO.expected_frame_counts(n_sections, window)
+    assert [(s["total_latent_frames"], s["pixel_frames"]) for s in res.sections] == counts
+    assert res.total_generated_latent_frames == counts[-1][0]
+    assert tuple(res.history_latents.shape) == (1, 16, counts[-1][0] + 19, 4, 4)
+    # first section: the end frame (scaled) is the post-context latent; later sections see the newest history
+    assert torch.all(calls[0]["clean"][:, :, 0] == -1.0) and torch.all(calls[0]["clean"][:, :, 1] == 3.5)
+    for i in range(1, len(calls)):
+        assert torch.all(calls[i]["clean"][:, :, 1] == float(i))              # first frame of the previous section
+        assert torch.all(calls[i]["two"] == float(i)) and calls[i]["four"].shape[2] == 16
+    # newest section first in the history; the last section is preceded by the start latent
+    assert torch.all(res.history_latents[:, :, 0] == -1.0)
+    assert torch.all(res.history_latents[:, :, 1:1 + window] == float(n_sections))
+    assert res.history_pixels.shape[2] == counts[-1][1] and res.history_pixels.shape[-1] == 32
+
+
+def test_one_frame_inference_path():
+    calls = []
+    sample_fn, decode_fn = _stubs(calls)
+    res = S.generate_sections(sample_fn, decode_fn, torch.zeros(1, 16, 1, 4, 4), 32, 32, 7, one_frame_inference=True)
+    assert len(calls) == 1 and calls[0]["T"] == 1 and calls[0]["two"] is None and calls[0]["latent_indices"] == [9]
+    assert res.total_generated_latent_frames == 1 and res.history_pixels.shape[2] == 1
