@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--config", default="13b", choices=["13b", "tiny"])
     ap.add_argument("--n-text", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp8", action="store_true",
+                    help="block linears on the fp8 MFMA (e4m3 activations: NOT the bf16 headline configuration)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -135,6 +137,8 @@ def main():
         model = HunyuanVideoTransformer3DModelPacked(**cfg_kw).to(bf)
     synthetic.init_synthetic_(dict(model.state_dict()), seed=0, fast_device_rng=True)
     model.eval()
+    if args.fp8:
+        model.enable_fp8_compute()
     if world > 1:
         model.enable_sequence_parallel()
 
@@ -203,7 +207,9 @@ def main():
             else "sec per 25-step section (tiny packed DiT)",
             "value": round(ms_per_step * 25 / 1e3, 4), "unit": "s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": False,
-            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "fp8-e4m3 block linears (opt-in, outside the 1e-2 parity bar) + bf16 attention" if args.fp8 else "bf16",
+            "data": "synthetic",
             "config": {"workload": workload, "packed_tokens": S, "image_tokens": Si, "text_tokens": St,
                        "teacache": False, "parallelism": "single GPU" if world == 1 else f"ulysses-sp{world}"},
             "model_tflops_per_step": round((24 * 3072 ** 2 * S + 4 * S * S * 3072) * 60 / 1e12, 1) if args.config == "13b" else None,

@@ -1,4 +1,5 @@
-// The MFMA GEMM pipeline shared by K5 (the DiT linears, bf16) and K11 (the VAE convolutions and linears, fp16):
+// The MFMA GEMM pipeline shared by K5 (the DiT linears, bf16), K6 (the same linears in e4m3 on the fp8 MFMA) and
+// K11 (the VAE convolutions and linears, fp16):
 // C = epilogue(A . W^T + bias), 16-bit in / fp32 accumulate / 16-bit out  (gfx950 MFMA 16x16x32, wave64)
 //
 // The nn.Linear of every DiT block (ref hunyuan_video_packed.py:119-121, 133-135, 154-156, 167-169, 552,
@@ -30,7 +31,7 @@
 
 namespace fp_gemm {
 
-constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int BM = 256, BN = 256, BK = 64;   // BK: K step of the 16-bit types (fp8: 128); always 128 B per row
 constexpr int OP_BYTES = BM * BK * 2;        // 32 KiB: one operand tile
 constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
 
@@ -43,17 +44,41 @@ struct ConvGeom {
     int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw;
 };
 
+// OCP e4m3 storage type of the fp8 path (K6): one byte per element, so a 128-B LDS row holds 128 K values.
+struct fp8e4 {
+    unsigned char bits;
+};
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+// One lane's operand for one 16-row tile and one K tile is two 16-B LDS reads h[0], h[1].
+//   16-bit types: two MFMA 16x16x32 (K = 32 each), one per read.
+//   fp8:          ONE MFMA 16x16x128 (the block-scaled f8f6f4 instruction with unit block scales: twice the
+//                 bf16 rate), whose 32-B operand is the two reads side by side.  Both operands are read with the
+//                 same lane -> K mapping, so the product does not depend on the instruction's K order.
 template <typename T> struct mfma_op;
 template <> struct mfma_op<bf16> {
-    typedef bf16x8 frag;
-    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    static constexpr int KS = 2;
+    static __device__ __forceinline__ f32x4 run(const i32x4 (&a)[2], const i32x4 (&b)[2], int ks, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[ks]),
+                                                       __builtin_bit_cast(bf16x8, b[ks]), c, 0, 0, 0);
     }
 };
 template <> struct mfma_op<_Float16> {
-    typedef _Float16 frag __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ f32x4 run(frag a, frag b, f32x4 c) {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    static constexpr int KS = 2;
+    static __device__ __forceinline__ f32x4 run(const i32x4 (&a)[2], const i32x4 (&b)[2], int ks, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a[ks]), __builtin_bit_cast(h8, b[ks]), c,
+                                                      0, 0, 0);
+    }
+};
+template <> struct mfma_op<fp8e4> {
+    static constexpr int KS = 1;
+    static __device__ __forceinline__ f32x4 run(const i32x4 (&a)[2], const i32x4 (&b)[2], int, f32x4 c) {
+        const i32x8 av = __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 bv = __builtin_shufflevector(b[0], b[1], 0, 1, 2, 3, 4, 5, 6, 7);
+        // cbsz = blgp = 0: both operands e4m3; scale operands 0 = no block scaling
+        return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, c, 0, 0, 0, 0, 0, 0);
     }
 };
 
@@ -73,17 +98,23 @@ __device__ __forceinline__ float gelu_tanh(float v) {
 
 // EPI: 0 bias | 1 bias+GELU | 2 bias+GELU on columns >= gelu_from | 3 R + gate*(.) | 4 R + (.)
 // AMODE: 0 = A is a row-major [M, K] matrix | 1 = A is gathered from a channels-last volume (ConvGeom)
-template <typename T, int EPI, int AMODE>
+// T = operand element type, TO = output / bias / residual / gate type.  a_scale [M] and w_scale [N] (fp32) are
+// the dequantisation factors of the fp8 path: C = epilogue(a_scale[m] * w_scale[n] * (A . W^T) + bias).
+template <typename T, typename TO, int EPI, int AMODE>
 __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__ A, int64_t lda,
                                                            int64_t a2_delta, int k1,
                                                            const T* __restrict__ W, int64_t ldw,
-                                                           const T* __restrict__ bias, T* __restrict__ C,
+                                                           const TO* __restrict__ bias, TO* __restrict__ C,
                                                            int64_t ldc, int M, int N, int K, int gelu_from,
-                                                           const T* __restrict__ R, int64_t ldr,
-                                                           const T* __restrict__ gate, int ntm, int ntn,
-                                                           ConvGeom cg) {
-    typedef typename mfma_op<T>::frag frag_t;
-    typedef T Tx4 __attribute__((ext_vector_type(4)));
+                                                           const TO* __restrict__ R, int64_t ldr,
+                                                           const TO* __restrict__ gate, int ntm, int ntn,
+                                                           ConvGeom cg, const float* __restrict__ a_scale,
+                                                           const float* __restrict__ w_scale) {
+    typedef i32x4 frag_t;
+    typedef TO Tx4 __attribute__((ext_vector_type(4)));
+    constexpr bool SCALED = sizeof(T) == 1;
+    constexpr int BKE = 128 / (int)sizeof(T);      // K elements per tile
+    constexpr int CE = 16 / (int)sizeof(T);        // elements per 16-B chunk
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2][A 32 KiB | W 32 KiB]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,24 +146,24 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
             wrow0[h][j] = (p >> 2) * 64 + h * 32 + (p & 3) * 8;
             const int ar = arow0[h][j] + prow, wrw = wrow0[h][j] + prow;
             if (AMODE == 0) {
-                pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + ((pch ^ ((ar >> 1) & 7)) << 3);
+                pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + (pch ^ ((ar >> 1) & 7)) * CE;
             } else {
                 const int m = min(m0 + ar, M - 1);
                 cw[h][j] = m % cg.Wo;
                 ch[h][j] = (m / cg.Wo) % cg.Ho;
                 ct[h][j] = m / (cg.Wo * cg.Ho);
-                cch[h][j] = (pch ^ ((ar >> 1) & 7)) << 3;
+                cch[h][j] = (pch ^ ((ar >> 1) & 7)) * CE;
             }
-            pw[h][j] = W + (int64_t)min(n0 + wrw, N - 1) * ldw + ((pch ^ ((wrw >> 1) & 7)) << 3);
+            pw[h][j] = W + (int64_t)min(n0 + wrw, N - 1) * ldw + (pch ^ ((wrw >> 1) & 7)) * CE;
         }
     auto issue_a = [&](int h, int t) {
         unsigned char* dst = smem + (t & 1) * BUF_BYTES;
         if (AMODE == 0) {
-            const int64_t koff = (int64_t)t * BK + ((t * BK >= k1) ? a2_delta : 0);
+            const int64_t koff = (int64_t)t * BKE + ((t * BKE >= k1) ? a2_delta : 0);
 #pragma unroll
             for (int j = 0; j < 2; ++j) dma16(pa[h][j] + koff, dst + arow0[h][j] * 128);
         } else {
-            const int k0 = t * BK;                  // one K tile lies inside one tap (Cin % 64 == 0)
+            const int k0 = t * BKE;                 // one K tile lies inside one tap (Cin % 64 == 0)
             const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
             const int dt = tap / 9 - 2, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
 #pragma unroll
@@ -148,19 +179,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
         }
     };
     auto issue_w = [&](int h, int t) {
-        const int64_t koff = (int64_t)t * BK;
+        const int64_t koff = (int64_t)t * BKE;
         unsigned char* dst = smem + (t & 1) * BUF_BYTES + OP_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; ++j) dma16(pw[h][j] + koff, dst + wrow0[h][j] * 128);
     };
 
-    // ---- fragment read offsets: lane reads tile row (lane & 15), chunk 4 ks + (lane >> 4), swizzled
+    // ---- fragment read offsets: lane reads tile row (lane & 15), swizzled chunks
+    //   16-bit: chunk (lane >> 4) for ks = 0 and that + 4 for ks = 1   |   fp8: chunks 2 (lane >> 4) and + 1
     const int fr = lane & 15, fq = lane >> 4;
-    const unsigned off_k0 = (unsigned)(fr * 128 + ((fq ^ (fr >> 1)) << 4));     // ks = 1: off_k0 ^ 64
+    constexpr unsigned SECOND = SCALED ? 16u : 64u;
+    const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
     const unsigned char* a_rd0 = smem + (wr * 128) * 128 + off_k0;
-    const unsigned char* a_rd1 = smem + (wr * 128) * 128 + (off_k0 ^ 64);
+    const unsigned char* a_rd1 = smem + (wr * 128) * 128 + (off_k0 ^ SECOND);
     const unsigned char* w_rd0 = smem + OP_BYTES + (wc * 64) * 128 + off_k0;
-    const unsigned char* w_rd1 = smem + OP_BYTES + (wc * 64) * 128 + (off_k0 ^ 64);
+    const unsigned char* w_rd1 = smem + OP_BYTES + (wc * 64) * 128 + (off_k0 ^ SECOND);
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -169,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     frag_t af[4][2], wf[2][2];
 
-    const int nk = K / BK;
+    const int nk = K / BKE;
 
     // ---- prologue: tile 0 whole, then the two half tiles of tile 1 that the loop does not issue itself
     issue_a(0, 0);
@@ -202,11 +235,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
     __builtin_amdgcn_s_barrier();                                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     __builtin_amdgcn_s_setprio(1);                                                                            \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < mfma_op<T>::KS; ++ks)                                             \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                      \
             _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                  \
                 acc[(MH) * 4 + mi][(NH) * 2 + ni] =                                                           \
-                    mfma_op<T>::run(wf[ni][ks], af[mi][ks], acc[(MH) * 4 + mi][(NH) * 2 + ni]);               \
+                    mfma_op<T>::run(wf[ni], af[mi], ks, acc[(MH) * 4 + mi][(NH) * 2 + ni]);                   \
     __builtin_amdgcn_s_setprio(0);                                                                            \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     __builtin_amdgcn_s_barrier();                                                                             \
@@ -261,13 +294,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
         Tx4 gv = {0, 0, 0, 0};
         if (EPI == 3) gv = *reinterpret_cast<const Tx4*>(gate + n);
         const bool do_gelu = EPI == 1 || (EPI == 2 && n >= gelu_from);
+        f32x4 ws = {1.f, 1.f, 1.f, 1.f};
+        if (SCALED) ws = *reinterpret_cast<const f32x4*>(w_scale + n);
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + wr * 128 + mi * 16 + fr;
             if (m >= M) continue;
             float v[4];
+            if (SCALED) {
+                const float as = a_scale[m];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + (float)bv[j];
+                for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] * (as * ws[j]) + (float)bv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = acc[mi][ni][j] + (float)bv[j];
+            }
             if (do_gelu) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
@@ -279,25 +320,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
             }
             Tx4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (T)v[j];
+            for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
             *reinterpret_cast<Tx4*>(C + (int64_t)m * ldc + n) = o;
         }
     }
 }
 
 
-template <typename T, int EPI, int AMODE>
+template <typename T, int EPI, int AMODE, typename TO = T>
 int launch(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
            void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
-           const void* gate, const ConvGeom& cg, hipStream_t st) {
+           const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
+           const float* w_scale = nullptr) {
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     constexpr int smem = 2 * BUF_BYTES;
-    auto kern = gemm_pipe_kernel<T, EPI, AMODE>;
+    auto kern = gemm_pipe_kernel<T, TO, EPI, AMODE>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     kern<<<dim3((unsigned)(ntm * ntn)), dim3(512), smem, st>>>((const T*)a, lda, a2_delta, k1, (const T*)w, ldw,
-                                                              (const T*)bias, (T*)c, ldc, M, N, K, gelu_from,
-                                                              (const T*)resid, ldr, (const T*)gate, ntm, ntn, cg);
+                                                              (const TO*)bias, (TO*)c, ldc, M, N, K, gelu_from,
+                                                              (const TO*)resid, ldr, (const TO*)gate, ntm, ntn, cg,
+                                                              a_scale, w_scale);
     FP_CHECK_LAUNCH();
     return 0;
 }

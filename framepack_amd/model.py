@@ -280,6 +280,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ws = {}                  # activation workspaces keyed by (S, device)
         self.taps = None               # optional dict: per-block outputs for parity tests
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
+        self.fp8_compute = False       # block linears on the fp8 MFMA (enable_fp8_compute)
 
     # ---- reference API ---------------------------------------------------------------------
     def install_image_projection(self, in_channels):
@@ -317,6 +318,19 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         if self.heads % self.sp_world != 0:
             raise ValueError(f"{self.heads} heads do not divide over {self.sp_world} ranks")
         self._ws = {}
+
+    def enable_fp8_compute(self, enable: bool = True):
+        """Run the linears of the double/single blocks on the gfx950 fp8 MFMA (K6): weights held as e4m3 with a
+        scale per output channel (a reference fp8 checkpoint's e4m3 weights and `scale_weight`, ref
+        utils/fp8_optimization_utils.py, are used as they are), activations quantised to e4m3 per token row in
+        front of every GEMM.  About twice the GEMM rate of bf16, but the activations lose bits the reference's
+        W8A16 path keeps: a block's output moves by a few per cent relative L2, outside the 1e-2 parity bar, so
+        this is off unless asked for.  Modulation, embedders, refiner and head stay bf16 (the reference
+        quantises only `transformer_blocks` / `single_transformer_blocks`, excluding "norm")."""
+        self.fp8_compute = bool(enable)
+        self._packed = None
+        self._ws = {}
+        return self
 
     def _attend(self, q, k, v, n_img):
         """Joint attention over [image rows | text rows]; output written over q."""
@@ -373,7 +387,19 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             return (w.to(sw.dtype) * sw).to(BF16)
         return w.to(BF16)
 
-    def _fuse(self, linears):
+    def _fuse_fp8(self, linears):
+        """(e4m3 weight [N,K], fp32 scale [N]) and the bf16 bias of the row-concatenated linears."""
+        qs, scs = [], []
+        for l in linears:
+            q, sc = ops.quantize_weight_fp8(l.weight.detach(), getattr(l, "scale_weight", None))
+            qs.append(q)
+            scs.append(sc)
+        b = torch.cat([l.bias.detach().to(BF16) for l in linears], dim=0).contiguous()
+        return (torch.cat(qs, dim=0).contiguous(), torch.cat(scs, dim=0).contiguous()), b
+
+    def _fuse(self, linears, block: bool = False):
+        if block and self.fp8_compute:
+            return self._fuse_fp8(linears)
         ws = [self._dense_weight(l) for l in linears]
         W = torch.cat(ws, dim=0).contiguous()
         b = torch.cat([l.bias.detach().to(BF16) for l in linears], dim=0).contiguous()
@@ -399,14 +425,14 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         for blk in self.transformer_blocks:
             a = blk.attn
             e = SimpleNamespace()
-            e.w_qkv, e.b_qkv = self._fuse([a.to_q, a.to_k, a.to_v])
-            e.w_qkv_c, e.b_qkv_c = self._fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj])
-            e.w_out, e.b_out = self._fuse([a.to_out[0]])
-            e.w_out_c, e.b_out_c = self._fuse([a.to_add_out])
-            e.w_ff1, e.b_ff1 = self._fuse([blk.ff.net[0].proj])
-            e.w_ff2, e.b_ff2 = self._fuse([blk.ff.net[2]])
-            e.w_ff1_c, e.b_ff1_c = self._fuse([blk.ff_context.net[0].proj])
-            e.w_ff2_c, e.b_ff2_c = self._fuse([blk.ff_context.net[2]])
+            e.w_qkv, e.b_qkv = self._fuse([a.to_q, a.to_k, a.to_v], block=True)
+            e.w_qkv_c, e.b_qkv_c = self._fuse([a.add_q_proj, a.add_k_proj, a.add_v_proj], block=True)
+            e.w_out, e.b_out = self._fuse([a.to_out[0]], block=True)
+            e.w_out_c, e.b_out_c = self._fuse([a.to_add_out], block=True)
+            e.w_ff1, e.b_ff1 = self._fuse([blk.ff.net[0].proj], block=True)
+            e.w_ff2, e.b_ff2 = self._fuse([blk.ff.net[2]], block=True)
+            e.w_ff1_c, e.b_ff1_c = self._fuse([blk.ff_context.net[0].proj], block=True)
+            e.w_ff2_c, e.b_ff2_c = self._fuse([blk.ff_context.net[2]], block=True)
             e.nq, e.nk = a.norm_q.weight.detach().to(BF16).contiguous(), a.norm_k.weight.detach().to(BF16).contiguous()
             e.nq_c = a.norm_added_q.weight.detach().to(BF16).contiguous()
             e.nk_c = a.norm_added_k.weight.detach().to(BF16).contiguous()
@@ -415,8 +441,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         for blk in self.single_transformer_blocks:
             a = blk.attn
             e = SimpleNamespace()
-            e.w_in, e.b_in = self._fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp])       # [k | v | q | mlp]
-            e.w_out, e.b_out = self._fuse([blk.proj_out])
+            e.w_in, e.b_in = self._fuse([a.to_k, a.to_v, a.to_q, blk.proj_mlp], block=True)       # [k | v | q | mlp]
+            e.w_out, e.b_out = self._fuse([blk.proj_out], block=True)
             e.nq, e.nk = a.norm_q.weight.detach().to(BF16).contiguous(), a.norm_k.weight.detach().to(BF16).contiguous()
             P.single.append(e)
             mods.append(blk.norm.linear)
@@ -444,6 +470,9 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                                  N=torch.empty((S, d), dtype=BF16, device=device),
                                  Y=torch.empty((S, 3 * d + m), dtype=BF16, device=device),
                                  acc=torch.zeros((2,), dtype=torch.float32, device=device))
+            if self.fp8_compute:                              # e4m3 image of one GEMM's A operand + row scales
+                ws.Q = torch.empty((S * (d + m),), dtype=ops.FP8, device=device)
+                ws.QS = torch.empty((S,), dtype=torch.float32, device=device)
             self._ws[key] = ws
         return ws
 
@@ -492,6 +521,15 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         return out[:Si].unsqueeze(0), rope
 
     # ---- the blocks -------------------------------------------------------------------------
+    @staticmethod
+    def _lin(ws, a, w, b, **kw):
+        """One block linear: bf16 GEMM, or (fp8 compute) row quantisation + fp8 GEMM."""
+        if not isinstance(w, tuple):
+            return ops.gemm(a, w, b, **kw)
+        M, K = a.shape
+        aq, asc = ops.quantize_rows_fp8(a, out=ws.Q[:M * K].view(M, K), scale=ws.QS[:M])
+        return ops.gemm_fp8(aq, asc, w[0], w[1], b, **kw)
+
     def _double_block(self, e, mod_i, mod_c, ws, Si, S, rope):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
@@ -500,31 +538,31 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         ops.layernorm_modulate(X[:Si], sc_a, sh_a, out=N[:Si])
         ops.layernorm_modulate(X[Si:], csc_a, csh_a, out=N[Si:])
         qkv = Y[:, :3 * d]
-        ops.gemm(N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
-        ops.gemm(N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
+        self._lin(ws, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
+        self._lin(ws, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
         q, k, v = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
         ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H, wq_txt=e.nq_c, wk_txt=e.nk_c)
         self._attend(q, k, v, Si)
-        ops.gemm(q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
-        ops.gemm(q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
+        self._lin(ws, q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
+        self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
         ops.layernorm_modulate(X[:Si], sc_m, sh_m, out=N[:Si])
         ops.layernorm_modulate(X[Si:], csc_m, csh_m, out=N[Si:])
         Fh = Y[:, 3 * d:]
-        ops.gemm(N[:Si], e.w_ff1, e.b_ff1, out=Fh[:Si], epilogue=ops.EPI_GELU)
-        ops.gemm(N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
-        ops.gemm(Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_m)
-        ops.gemm(Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_m)
+        self._lin(ws, N[:Si], e.w_ff1, e.b_ff1, out=Fh[:Si], epilogue=ops.EPI_GELU)
+        self._lin(ws, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
+        self._lin(ws, Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_m)
+        self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_m)
 
     def _single_block(self, e, mod, ws, Si, S, rope):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         shift, scale, gate = mod.chunk(3)
         ops.layernorm_modulate(X, scale, shift, out=N)
-        ops.gemm(N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)   # [k | v | q | gelu(mlp)]
+        self._lin(ws, N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)   # [k | v | q | gelu(mlp)]
         k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
         ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H)
         self._attend(q, k, v, Si)
-        ops.gemm(Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
+        self._lin(ws, Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
 
     def _run_blocks(self, P, mods, ws, Si, S, rope):
         d = self.inner_dim

@@ -213,6 +213,78 @@ def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
     return out
 
 
+# ---- K6: fp8 linears on the fp8 MFMA (opt-in: e4m3 activations are outside the 1e-2 parity bar) -------------
+
+FP8 = torch.float8_e4m3fn
+FP8_MAX = 448.0
+
+
+def quantize_weight_fp8(weight: torch.Tensor, scale: Optional[torch.Tensor] = None):
+    """Host-side weight preparation: [N,K] -> (e4m3 [N,K], fp32 scale [N]).  With `scale` (the per-tensor
+    `scale_weight` of a reference fp8 checkpoint, ref utils/fp8_optimization_utils.py) the weight is already
+    e4m3 and the scale is only broadcast; otherwise one scale per output channel is derived (amax / 448)."""
+    N = weight.shape[0]
+    if weight.dtype == FP8:
+        assert scale is not None
+        return weight.contiguous(), scale.float().reshape(-1).expand(N).contiguous()
+    w = weight.float()
+    sc = (w.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-12)
+    return (w / sc[:, None]).to(FP8).contiguous(), sc.contiguous()
+
+
+def quantize_rows_fp8(x: torch.Tensor, x2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                      scale: Optional[torch.Tensor] = None):
+    """K6a: bf16 [M,K1] (+ [M,K2] side by side in K) -> (e4m3 [M,K], fp32 scale [M]); one scale per token row."""
+    _dev(x, x2, out, scale)
+    x_, M, K1, ld1 = _rows2d(x)
+    assert x.dtype == BF16
+    K2, ld2, x2p = 0, 0, None
+    if x2 is not None:
+        x2_, M2, K2, ld2 = _rows2d(x2)
+        assert M2 == M and x2.dtype == BF16
+        x2p = x2_.data_ptr()
+    if out is None:
+        out = torch.empty((M, K1 + K2), dtype=FP8, device=x.device)
+    if scale is None:
+        scale = torch.empty((M,), dtype=torch.float32, device=x.device)
+    assert out.dtype == FP8 and out.shape == (M, K1 + K2) and out.stride(1) == 1
+    assert scale.dtype == torch.float32 and scale.numel() == M and scale.is_contiguous()
+    _lib.check(_lib.load().fp_quantize_rows_fp8(x_.data_ptr(), ld1, K1, x2p, ld2, K2, out.data_ptr(), out.stride(0),
+                                                scale.data_ptr(), M, _stream(x)), "fp_quantize_rows_fp8")
+    return out, scale
+
+
+def gemm_fp8(a_q: torch.Tensor, a_scale: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor,
+             bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS,
+             gelu_from: int = 0, resid: Optional[torch.Tensor] = None,
+             gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K6b: out bf16 = epilogue(a_scale[m] * w_scale[n] * (a_q @ w_q.T) + bias); a_q [M,K], w_q [N,K] e4m3."""
+    _dev(a_q, a_scale, w_q, w_scale, bias, out, resid, gate)
+    M, K = a_q.shape
+    N, Kw = w_q.shape
+    assert a_q.dtype == FP8 and w_q.dtype == FP8 and K == Kw and a_q.stride(1) == 1 and w_q.stride(1) == 1
+    assert a_scale.dtype == torch.float32 and a_scale.numel() == M and a_scale.is_contiguous()
+    assert w_scale.dtype == torch.float32 and w_scale.numel() == N and w_scale.is_contiguous()
+    assert bias is None or (bias.dtype == BF16 and bias.numel() == N)
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=a_q.device)
+    o_, Mo, No, ldc = _rows2d(out)
+    assert (Mo, No) == (M, N) and out.dtype == BF16
+    ldr, rptr, gptr = 0, None, None
+    if epilogue in (EPI_GATE_RESIDUAL, EPI_RESIDUAL):
+        r_, Mr, Nr, ldr = _rows2d(resid)
+        assert (Mr, Nr) == (M, N) and resid.dtype == BF16
+        rptr = r_.data_ptr()
+    if epilogue == EPI_GATE_RESIDUAL:
+        gate = gate.reshape(-1).contiguous()
+        assert gate.numel() == N and gate.dtype == BF16
+        gptr = gate.data_ptr()
+    _lib.check(_lib.load().fp_gemm_fp8_bf16(a_q.data_ptr(), a_q.stride(0), a_scale.data_ptr(), w_q.data_ptr(),
+                                            w_q.stride(0), w_scale.data_ptr(), _ptr(bias), o_.data_ptr(), ldc, M, N, K,
+                                            epilogue, gelu_from, rptr, ldr, gptr, _stream(a_q)), "fp_gemm_fp8_bf16")
+    return out
+
+
 # ---- K11: causal-3D VAE decode (fp16, channels-last volumes) ------------------------------------------------
 
 def conv3d_causal(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],

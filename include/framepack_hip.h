@@ -88,6 +88,23 @@ int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void*
                  const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
                  const void* resid, int64_t ldr, const void* gate, void* stream);
 
+/* ---- K6: fp8 linears on the gfx950 fp8 MFMA ---------------------------------------------------------------
+ * Replaces the patched nn.Linear.forward of utils/fp8_optimization_utils.py (fp8_linear_forward_patch: e4m3
+ * weight * scale_weight, then F.linear) with a GEMM that multiplies in e4m3.  Opt-in: quantised activations move
+ * a block's output by 2-4 % relative L2, outside the 1e-2 bar of the bf16 path. */
+
+/* x1 [M, K1] (and optionally x2 [M, K2], laid after it in K) bf16 -> q [M, K1+K2] e4m3 (OCP, max 448) and
+ * scale [M] fp32 with x ~= scale[m] * q.  K1, K2 % 8 == 0; ldq (bytes = elements) % 8 == 0 (% 16 to feed fp_gemm_fp8_bf16). */
+int fp_quantize_rows_fp8(const void* x1, int64_t ld1, int K1, const void* x2, int64_t ld2, int K2, void* q,
+                         int64_t ldq, void* scale, int M, void* stream);
+
+/* c [M, N] bf16 = epilogue(a_scale[m] * w_scale[n] * (a . w^T) + bias): a [M, K] and w [N, K] e4m3, K % 128 == 0,
+ * lda/ldw % 16 == 0, a_scale [M] and w_scale [N] fp32 (w_scale 16-byte aligned; a per-tensor scale_weight is
+ * passed broadcast to N entries).  bias/resid/gate bf16; epilogue and the remaining arguments as fp_gemm_bf16. */
+int fp_gemm_fp8_bf16(const void* a, int64_t lda, const void* a_scale, const void* w, int64_t ldw,
+                     const void* w_scale, const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue,
+                     int gelu_from, const void* resid, int64_t ldr, const void* gate, void* stream);
+
 /* ---- K11: causal-3D VAE decode (fp16, channels-last [T, H, W, C] volumes) -------------------------------
  * The reference's code for this path is diffusers_helper/hunyuan.py:93-103 (vae_decode); everything under its
  * `vae.decode(...)` call is diffusers 0.33.1 AutoencoderKLHunyuanVideo (third-party, absent from the reference

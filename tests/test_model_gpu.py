@@ -157,6 +157,56 @@ def test_fp8_weights_follow_reference_w8a16_semantics(tiny):
     assert rel_l2(got, ref) < TOL
 
 
+def test_fp8_compute_mode_tracks_bf16_and_switches_off_cleanly():
+    """enable_fp8_compute(): block linears on the fp8 MFMA with e4m3 activations.  NOT a parity path (e4m3
+    activations cannot meet 1e-2); the check is that it tracks the bf16 result to quantisation accuracy, block by
+    block, and that switching it off restores the bf16 path bit for bit."""
+    m, _ = build(synthetic.CONFIG_TINY)
+    kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES["config1"]))
+    m.taps = {}
+    base = m(return_dict=False, **kw)[0]
+    taps16 = m.taps
+    m.enable_fp8_compute()
+    m.taps = {}
+    got = m(return_dict=False, **kw)[0]
+    taps8, m.taps = m.taps, None
+    assert isinstance(m._packed.double[0].w_qkv, tuple) and m._packed.double[0].w_qkv[0].dtype == torch.float8_e4m3fn
+    worst = 0.0
+    for name in taps16:
+        if name.startswith(("double.", "single.")):
+            for a, b in zip(taps8[name], taps16[name]):
+                worst = max(worst, rel_l2(a, b))
+    d = rel_l2(got, base)
+    print(f"fp8 compute vs bf16: worst block rel-L2 {worst:.4f}, output rel-L2 {d:.4f}")
+    assert 1e-3 < worst < 8e-2 and 1e-3 < d < 0.12
+    m.enable_fp8_compute(False)
+    again = m(return_dict=False, **kw)[0]
+    assert torch.equal(again, base)
+
+
+def test_fp8_compute_mode_uses_reference_checkpoint_bytes_and_scales():
+    """With a reference fp8 checkpoint (e4m3 weight + per-tensor scale_weight) the fp8-compute path multiplies by
+    exactly those bytes: the only difference to the W8A16 path is the activation quantisation."""
+    from oracle import fp8_oracle as F8
+    m, _ = build(synthetic.CONFIG_TINY)
+    q = F8.quantize_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    m8 = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_TINY).to(BF)
+    for name, mod in m8.named_modules():
+        if name + ".scale_weight" in q:
+            mod.register_buffer("scale_weight", torch.tensor(1.0, dtype=BF))
+    m8.load_state_dict(q, strict=True, assign=True)
+    m8 = m8.to(DEV).eval()
+    kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES["config1"]))
+    w8a16 = m8(return_dict=False, **kw)[0]
+    m8.enable_fp8_compute()
+    w8a8 = m8(return_dict=False, **kw)[0]
+    wq, wsc = m8._packed.single[0].w_out
+    key = "single_transformer_blocks.0.proj_out"
+    assert torch.equal(wq.view(torch.uint8).cpu(), q[key + ".weight"].view(torch.uint8))
+    assert torch.all(wsc.cpu() == q[key + ".scale_weight"].float())
+    assert 1e-3 < rel_l2(w8a8, w8a16) < 0.12
+
+
 def test_full_width_blocks_match_oracle():
     """13B width (24 heads x 128, d = 3072, mlp 12288), 1 double + 1 single block, 320x320x33f section
     (S = 5 585 tokens): per-block rel-L2 against the fp32 oracle."""
