@@ -1,5 +1,12 @@
 // K5: the nn.Linear of every DiT block, bf16 (kernel: gemm_pipeline.h).
-#include "gemm_pipeline.h"
+#include "gemm_w4.h"
+
+static int g_variant = 1;      // 0: 8-wave ping-pong pipeline | 1: one wave per SIMD
+extern "C" int fp_debug_gemm_variant(int v) {
+    const int old = g_variant;
+    if (v >= 0) g_variant = v;
+    return old;
+}
 
 extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
                             const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue,
@@ -11,7 +18,16 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
     if (M == 0) return 0;
     const ConvGeom cg{};
     hipStream_t st = (hipStream_t)stream;
-#define FP_CASE(E) case E: return launch<bf16, E, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st)
+    // the 4-wave kernel moves output (and residual) rows 16 B per lane; operands aligned only to the 8 B the
+    // contract asks for go to the 8-wave kernel
+    const bool wide = ((uintptr_t)c & 15) == 0 && ldc % 8 == 0 && (epilogue < 3 || (((uintptr_t)resid & 15) == 0 && ldr % 8 == 0));
+    const bool w4 = (g_variant & 1) && wide;
+#define FP_CASE(E)                                                                                                  \
+    case E:                                                                                                         \
+        return w4 ? launch_w4<bf16, E, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from,    \
+                                                 resid, ldr, gate, cg, st)                                          \
+                         : launch<bf16, E, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, \
+                                              ldr, gate, cg, st)
     switch (epilogue) {
         FP_CASE(0);
         FP_CASE(1);

@@ -89,11 +89,13 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
 }
 
+// tanh-GELU as v * sigmoid(2u), u = sqrt(2/pi) (v + 0.044715 v^3):  v / (1 + 2^(-2u log2 e)).
+// Two transcendentals (v_exp_f32, v_rcp_f32) and four plain VALU per value; the approximate reciprocal (1 ulp) is far
+// inside the 16-bit output rounding.
 __device__ __forceinline__ float gelu_tanh(float v) {
-    const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
-    const float e = __expf(2.f * u);
-    const float th = 1.f - 2.f / (e + 1.f);
-    return 0.5f * v * (1.f + th);
+    constexpr float k = 2.f * 0.7978845608028654f * 1.4426950408889634f;
+    const float z = v * __builtin_fmaf(v * v, 0.044715f * k, k);
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-z));
 }
 
 // EPI: 0 bias | 1 bias+GELU | 2 bias+GELU on columns >= gelu_from | 3 R + gate*(.) | 4 R + (.)

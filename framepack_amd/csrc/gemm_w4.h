@@ -1,0 +1,433 @@
+// Second-generation GEMM main loop: ONE wave per SIMD (4 waves = one 256 x 256 output tile), each wave owning a
+// 128 x 128 block whose 256 accumulator registers live in the AGPR half of the register file.
+//
+// Why (measured, profiles/r1_e_gemm_pmc.md): the 8-wave ping-pong pipeline of gemm_pipeline.h keeps the matrix pipe
+// 72 % busy (two barriers per 16 MFMAs); the rest is hand-off.  With one wave per SIMD there is nothing to hand
+// off: the wave interleaves its own LDS reads and LDS-DMA issues between MFMAs and meets the other three waves
+// only twice per K tile (every 64 MFMAs = 1024 matrix-pipe cycles).
+//
+// Same LDS image, swizzle, operand swap (token row on the lane) and epilogues as gemm_pipeline.h.
+//   * K tile = 64 (128 B per row), two 64 KiB buffers, staged as THREE units per tile: A-h0 / A-h1 (rows 0-63 /
+//     64-127 of each wave row) and W (whole).  A K tile is two phases: phase p multiplies A-h{p} (4 row tiles)
+//     with all of W (8 column tiles, fragments kept in registers across both phases) = 64 MFMAs.
+//   * A unit is re-staged right after the barrier that follows its last read: during P0(t) the wave issues
+//     A-h1(t+1), during P1(t) A-h0(t+2) and W(t+2); every unit is in flight for >= 2 phases, and the waits are
+//     counted (vmcnt 16 before every phase), never 0.  Loads past the last tile are clamped to it (they land
+//     in a buffer nobody reads), so the loop body has no branch and stays one scheduling region.
+//   * The last two MFMA groups of a phase are issued AFTER the next barrier, behind the first LDS reads of the
+//     new phase, so the read latency after a barrier is covered by 256 cycles of matrix work.
+#pragma once
+#include <type_traits>
+#include "gemm_pipeline.h"
+
+namespace fp_gemm {
+
+template <int N> using ic = std::integral_constant<int, N>;
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(ic<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// Makes the kernel descriptor reserve all 256 AGPRs (the asm below addresses them by number).
+__device__ __forceinline__ void reserve_agprs() {
+    asm volatile("" ::: "a0", "a255");
+}
+
+// a[IDX:IDX+3] (+)= w . a   (operands swapped as in gemm_pipeline.h: the token row ends up on the lane)
+template <typename T, int IDX, bool ZERO_C>
+__device__ __forceinline__ void mfma_acc(const i32x4& w, const i32x4& a) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        if constexpr (ZERO_C)
+            asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, 0" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
+        else
+            asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
+    } else {
+        if constexpr (ZERO_C)
+            asm volatile("v_mfma_f32_16x16x32_f16 a[%0:%1], %2, %3, 0" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
+        else
+            asm volatile("v_mfma_f32_16x16x32_f16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
+    }
+}
+template <int IDX> __device__ __forceinline__ f32x4 acc_read() {
+    float r0, r1, r2, r3;
+    asm volatile("v_accvgpr_read_b32 %0, a[%4]\nv_accvgpr_read_b32 %1, a[%5]\nv_accvgpr_read_b32 %2, a[%6]\n"
+                 "v_accvgpr_read_b32 %3, a[%7]"
+                 : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3)
+                 : "n"(IDX), "n"(IDX + 1), "n"(IDX + 2), "n"(IDX + 3));
+    return f32x4{r0, r1, r2, r3};
+}
+
+template <typename T, typename TO, int EPI, int AMODE>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A, int64_t lda, int64_t a2_delta,
+                                                         int k1, const T* __restrict__ W, int64_t ldw,
+                                                         const TO* __restrict__ bias, TO* __restrict__ C,
+                                                         int64_t ldc, int M, int N, int K, int gelu_from,
+                                                         const TO* __restrict__ R, int64_t ldr,
+                                                         const TO* __restrict__ gate, int ntm, int ntn, ConvGeom cg,
+                                                         const float* __restrict__ a_scale,
+                                                         const float* __restrict__ w_scale) {
+    typedef i32x4 frag_t;
+    typedef TO Tx4 __attribute__((ext_vector_type(4)));
+    constexpr bool SCALED = sizeof(T) == 1;
+    constexpr int BKE = 128 / (int)sizeof(T);
+    constexpr int CE = 16 / (int)sizeof(T);
+    constexpr int KS = mfma_op<T>::KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2][A 32 KiB | W 32 KiB] + stage 32 KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // ---- DMA sources.  One instruction = 8 tile rows x 128 B.  A half unit = 16 instructions (4 per wave),
+    //      W unit = 32 instructions (8 per wave).
+    const int prow = lane >> 3, pch = lane & 7;
+    const T* pa[2][4];
+    const T* pw[8];
+    int arow0[2][4], wrow0[8];
+    int ct[2][4], ch[2][4], cw[2][4], cch[2][4];
+    int m0 = 0, n0 = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave * 4 + j;                                // 0..15
+            arow0[h][j] = (i >> 3) * 128 + h * 64 + (i & 7) * 8;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wrow0[j] = (wave * 8 + j) * 8;
+
+    // tile order: XCD-contiguous, grouped 8 row-tiles tall so that co-running tiles share A and W panels.  The
+    // workgroup is persistent: it takes tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or
+    // the whole tile count, so vb & 7 stays this workgroup's XCD).
+    const int ntiles = ntm * ntn;
+    auto setup = [&](int vb) {
+        constexpr int GM = 8;
+        const int wid = xcd_remap(vb, ntiles);
+        const int per_group = GM * ntn;
+        const int group = wid / per_group, in_group = wid % per_group;
+        const int first_m = group * GM;
+        const int gsz = min(ntm - first_m, GM);
+        const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+        m0 = tm * BM;
+        n0 = tn * BN;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ar = arow0[h][j] + prow;
+                if (AMODE == 0) {
+                    pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + (pch ^ ((ar >> 1) & 7)) * CE;
+                } else {
+                    const int m = min(m0 + ar, M - 1);
+                    cw[h][j] = m % cg.Wo;
+                    ch[h][j] = (m / cg.Wo) % cg.Ho;
+                    ct[h][j] = m / (cg.Wo * cg.Ho);
+                    cch[h][j] = (pch ^ ((ar >> 1) & 7)) * CE;
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int wrw = wrow0[j] + prow;
+            pw[j] = W + (int64_t)min(n0 + wrw, N - 1) * ldw + (pch ^ ((wrw >> 1) & 7)) * CE;
+        }
+    };
+    const int nk = K / BKE;
+    auto issue_a1 = [&](int h, int j, int t) {
+        t = min(t, nk - 1);
+        unsigned char* dst = smem + (t & 1) * BUF_BYTES;
+        if (AMODE == 0) {
+            const int64_t koff = (int64_t)t * BKE + ((t * BKE >= k1) ? a2_delta : 0);
+            dma16(pa[h][j] + koff, dst + arow0[h][j] * 128);
+        } else {
+            const int k0 = t * BKE;
+            const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
+            const int dt = tap / 9 - 2, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
+            const int tu = max(ct[h][j] + dt, 0);
+            const int hu = min(max(ch[h][j] + dh, 0), cg.Ho - 1);
+            const int wu = min(max(cw[h][j] + dw, 0), cg.Wo - 1);
+            const int ts = cg.st ? ((tu + 1) >> 1) : tu;
+            const int hs = hu >> cg.sh, ws = wu >> cg.sw;
+            const int64_t off = ((int64_t)(ts * cg.Hi + hs) * cg.Wi + ws) * cg.Cin + c0 + cch[h][j];
+            dma16(A + off, dst + arow0[h][j] * 128);
+        }
+    };
+    auto issue_w1 = [&](int j, int t) {
+        t = min(t, nk - 1);
+        dma16(pw[j] + (int64_t)t * BKE, smem + (t & 1) * BUF_BYTES + OP_BYTES + wrow0[j] * 128);
+    };
+    // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (28 loads per wave)
+    auto prologue = [&] {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_a1(0, j, 0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_w1(j, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_a1(1, j, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) issue_a1(0, j, 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) issue_w1(j, 1);
+    };
+
+    // ---- fragment read offsets (as gemm_pipeline.h)
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr unsigned SECOND = SCALED ? 16u : 64u;
+    const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
+    // One address register per (buffer, K step) and operand; every other offset is an immediate below 64 KiB.  The
+    // second buffer's bases are made opaque so that the compiler does not fold them into 30-odd distinct addresses.
+    unsigned a_rd[2][2], w_rd[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        a_rd[0][ks] = (unsigned)(wr * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
+        w_rd[0][ks] = (unsigned)(wc * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
+        a_rd[1][ks] = a_rd[0][ks] + BUF_BYTES;
+        w_rd[1][ks] = w_rd[0][ks] + BUF_BYTES;
+        asm volatile("" : "+v"(a_rd[1][ks]), "+v"(w_rd[1][ks]));
+    }
+
+    // The 64 accumulator tiles live in AGPRs a[0:255] that the compiler never sees: tile (mi, ni) = a[(mi*8+ni)*4 .. +3].
+    // hipcc cannot keep 256 loop-carried accumulator registers in place once the MFMAs are interleaved with loads:
+    // whether they come from the MFMA builtin or from "+a" asm operands, it renames tiles and copies them through
+    // VGPRs (hundreds of v_accvgpr moves per K tile, or spills).  So the MFMAs and the final reads are inline asm
+    // on literal register numbers, the reservation below makes the kernel descriptor count the AGPRs, and the
+    // kernel keeps its VGPR need below 256 so that the compiler never reaches for an AGPR as spill space
+    // (tests/test_host_cpu.py checks the built code object for that).  The first K step of a tile multiplies onto
+    // a zero C operand: no zero fill.
+    reserve_agprs();
+
+    // W fragments of the current K tile: [ks][ni].  A fragments: a ring of 4 groups; group g of a phase =
+    // (ks = g >> 2, mi = 4 p + (g & 3)).
+    frag_t wf[2][8], af[4];
+
+    auto rd_a = [&](auto BUF, auto P, auto G) {
+        af[G & 3] = *reinterpret_cast<const frag_t*>(smem + a_rd[BUF][G >> 2] + (P * 64 + (G & 3) * 16) * 128);
+    };
+    auto rd_w = [&](auto BUF, auto KS_, auto NI) {
+        wf[KS_][NI] = *reinterpret_cast<const frag_t*>(smem + w_rd[BUF][KS_] + OP_BYTES + (NI * 16) * 128);
+    };
+    // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0)
+    auto mfma1 = [&](auto P, auto G, auto NI, auto ZC) {
+        constexpr int MI = P * 4 + (G & 3);
+        mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0)>(wf[G >> 2][NI], af[G & 3]);
+    };
+    // what is issued behind MFMA k of group g: at most one LDS read or one LDS-DMA per MFMA gap.
+    //   P0(t) issues A-h1(t+1);  P1(t) issues A-h0(t+2) and W(t+2)  (W's fragments sit in registers after P0).
+    auto slot = [&](auto BUF, auto P, int t, auto G, auto K_) {
+        constexpr int g = G, k = K_;
+        if constexpr (k == 0) rd_a(BUF, P, ic<g + 2>{});
+        if constexpr (P == 0) {
+            if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * (g < 4 ? g : 0)>{});
+            if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * (g < 4 ? g : 0) + 1>{});
+            if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1);
+        } else {
+            if constexpr (k == 2) {
+                if constexpr (g < 4) issue_a1(0, g, t + 2);
+                else issue_w1(g - 4, t + 2);
+            }
+            if constexpr (k == 5) issue_w1(2 + g, t + 2);
+        }
+    };
+    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+    // relaxed: the 32 output stores of the previous tile may still be in flight behind the loads this phase needs
+    // (memory operations retire in order), so the count that guarantees the loads is 16 + 32.
+    auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed) {
+        if (relaxed) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        fence();
+        if constexpr (P == 0) static_for<8>([&](auto ni) { rd_w(BUF, ic<0>{}, ni); });
+        rd_a(BUF, P, ic<0>{});
+        rd_a(BUF, P, ic<1>{});
+        fence();
+        if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind
+            static_for<8>([&](auto ni) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}); });
+            static_for<8>([&](auto ni) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}); });
+        }
+        fence();
+        static_for<6>([&](auto g) {
+            static_for<8>([&](auto k) {
+                mfma1(P, g, k, ZC);
+                fence();
+                slot(BUF, P, t, g, k);
+                fence();
+            });
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    // ---- epilogue of the tile at (em0, en0): lane (fr,fq) holds row em0 + wr*128 + mi*16 + fr,
+    //      columns en0 + wc*128 + ni*16 + 4 fq + (0..3)
+    // Output rows leave through a wave-private LDS stage (the 32 KiB above the operand buffers, 2 x 4 KiB per
+    // wave): the accumulator layout (lane = row, 4 columns) is rewritten as rows of 256 B, so every global store -
+    // and every residual load - is 16 B per lane and covers whole 128-byte lines (4 rows x 256 B per instruction).
+    // Stage image: [16 rows][256 B], 16-B chunk index XORed with the row (conflict-free b128 reads, 2-way b64 writes).
+    typedef TO Tx8 __attribute__((ext_vector_type(8)));
+    Tx8 rpre[2][4];          // EPI 3/4: residual rows (row layout) of two row tiles, a ring filled 2 tiles ahead
+    auto load_resid = [&](int em0, int en0, int mi) {
+        const int gcol = en0 + wc * 128 + (lane & 15) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = em0 + wr * 128 + mi * 16 + (lane >> 4) + 4 * i;
+            rpre[mi & 1][i] = Tx8{};
+            if (gcol < N && m < M) rpre[mi & 1][i] = *reinterpret_cast<const Tx8*>(R + (int64_t)m * ldr + gcol);
+        }
+    };
+    auto epilogue = [&](int em0, int en0) {
+        unsigned stage_off = 2 * BUF_BYTES + wave * 8192;      // opaque, so that the 4096 of the second stage buffer
+        asm volatile("" : "+v"(stage_off));                    // stays an instruction immediate, not 12 more addresses
+        unsigned char* stage = smem + stage_off;
+        Tx4 bv[8], gv[8];
+        f32x4 ws[8];
+        const int nb = en0 + wc * 128 + 4 * fq;
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const int n = min(nb + ni * 16, N - 4);
+            bv[ni] = Tx4{0, 0, 0, 0};
+            if (bias) bv[ni] = *reinterpret_cast<const Tx4*>(bias + n);
+            if (EPI == 3) gv[ni] = *reinterpret_cast<const Tx4*>(gate + n);
+            if (SCALED) ws[ni] = *reinterpret_cast<const f32x4*>(w_scale + n);
+        }
+        const int lrow = lane >> 4, lchk = lane & 15;
+        const int gcol = en0 + wc * 128 + lchk * 8;            // first of this lane's 8 columns in row layout
+        const bool col_ok = gcol < N;                          // N % 8 == 0: a chunk is inside or outside
+        static_for<8>([&](auto MI_) {
+            constexpr int mi = MI_;
+            unsigned char* sb = stage + (mi & 1) * 4096;
+            const int mrow0 = em0 + wr * 128 + mi * 16;
+            if (mrow0 >= M) return;                            // wave-uniform
+            if (EPI == 3 || EPI == 4) {                        // residual rows: registers (row layout) -> stage
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = lrow + 4 * i;
+                    *reinterpret_cast<Tx8*>(sb + row * 256 + ((lchk ^ row) << 4)) = rpre[mi & 1][i];
+                }
+                if (mi + 2 < 8) load_resid(em0, en0, mi + 2);
+            }
+            const float as = SCALED ? a_scale[min(mrow0 + fr, M - 1)] : 1.f;
+            static_for<8>([&](auto NI_) {
+                constexpr int ni = NI_;
+                const int n = nb + ni * 16;
+                unsigned char* sp = sb + fr * 256 + ((((ni * 2) + (fq >> 1)) ^ fr) << 4) + (fq & 1) * 8;
+                const f32x4 av = acc_read<(mi * 8 + ni) * 4>();
+                const bool do_gelu = EPI == 1 || (EPI == 2 && n >= gelu_from);
+                float v[4];
+                if (SCALED) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = av[j] * (as * ws[ni][j]) + (float)bv[ni][j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = av[j] + (float)bv[ni][j];
+                }
+                if (do_gelu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_tanh(v[j]);
+                }
+                if (EPI == 3 || EPI == 4) {
+                    const Tx4 rv = *reinterpret_cast<const Tx4*>(sp);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (float)rv[j] + (EPI == 3 ? (float)gv[ni][j] : 1.f) * v[j];
+                }
+                Tx4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (TO)v[j];
+                *reinterpret_cast<Tx4*>(sp) = o;
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = lrow + 4 * i;
+                const Tx8 ov = *reinterpret_cast<const Tx8*>(sb + row * 256 + ((lchk ^ row) << 4));
+                if (col_ok && mrow0 + row < M) *reinterpret_cast<Tx8*>(C + (int64_t)(mrow0 + row) * ldc + gcol) = ov;
+            }
+        });
+    };
+
+    static_assert(KS == 2, "the 4-wave main loop is written for the 16-bit MFMA 16x16x32");
+    int vb = blockIdx.x;
+    setup(vb);
+    prologue();
+    bool relaxed = false;
+    for (;;) {
+        const int em0 = m0, en0 = n0;
+        phase(ic<0>{}, ic<0>{}, 0, ic<0>{}, ic<1>{}, relaxed);
+        phase(ic<0>{}, ic<1>{}, 0, ic<1>{}, ic<1>{}, relaxed);
+        int t = 1;
+        if (nk > 1) {
+            phase(ic<1>{}, ic<0>{}, 1, ic<1>{}, ic<0>{}, relaxed);
+            phase(ic<1>{}, ic<1>{}, 1, ic<1>{}, ic<0>{}, false);
+            for (t = 2; t + 1 < nk; t += 2) {
+                phase(ic<0>{}, ic<0>{}, t, ic<1>{}, ic<0>{}, false);
+                phase(ic<0>{}, ic<1>{}, t, ic<1>{}, ic<0>{}, false);
+                phase(ic<1>{}, ic<0>{}, t + 1, ic<1>{}, ic<0>{}, false);
+                phase(ic<1>{}, ic<1>{}, t + 1, ic<1>{}, ic<0>{}, false);
+            }
+            if (t < nk) {
+                phase(ic<0>{}, ic<0>{}, t, ic<1>{}, ic<0>{}, false);
+                phase(ic<0>{}, ic<1>{}, t, ic<1>{}, ic<0>{}, false);
+            }
+        }
+        fence();
+        static_for<8>([&](auto ni) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}); });
+        static_for<8>([&](auto ni) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}); });
+        fence();
+        // every wave is done with the LDS (and the clamped tail loads have landed): the next tile's first loads
+        // go out BEFORE this tile's epilogue, whose stores then drain under the next main loop
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (EPI == 3 || EPI == 4) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) load_resid(em0, en0, mi);
+        }
+        fence();
+        vb += gridDim.x;
+        const bool more = vb < ntiles;
+        if (more) {
+            setup(vb);
+            prologue();
+        }
+        fence();
+        asm volatile("s_nop 15\ns_nop 15" ::: "memory");        // the last MFMAs retire before their tiles are read
+        epilogue(em0, en0);
+        if (!more) break;
+        // the operand pointers are recomputed rather than kept across the epilogue (32 VGPRs it needs itself)
+        asm volatile("" : "+s"(vb));
+        setup(vb);
+        // a ragged tile skips stores, so the relaxed count would not cover the loads: drain instead
+        if (em0 + BM > M || en0 + BN > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        relaxed = true;
+    }
+}
+
+// one workgroup per CU (the LDS footprint allows no more); a multiple of 8 so that a workgroup's tiles stay on its XCD
+inline int persistent_grid() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8)
+            cus = 256;
+        n = cus / 8 * 8;
+    }
+    return n;
+}
+
+template <typename T, int EPI, int AMODE, typename TO = T>
+int launch_w4(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
+              void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
+              const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
+              const float* w_scale = nullptr) {
+    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    constexpr int smem = 2 * BUF_BYTES + 4 * 8192;        // operand buffers + the epilogue's row stage
+    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    kern<<<dim3((unsigned)min(ntm * ntn, persistent_grid())), dim3(256), smem, st>>>((const T*)a, lda, a2_delta, k1, (const T*)w, ldw,
+                                                              (const TO*)bias, (TO*)c, ldc, M, N, K, gelu_from,
+                                                              (const TO*)resid, ldr, (const TO*)gate, ntm, ntn, cg,
+                                                              a_scale, w_scale);
+    FP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace fp_gemm
