@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     const T* pa[2][4];
     const T* pw[8];
     int arow0[2][4], wrow0[8];
-    int ct[2][4], ch[2][4], cw[2][4], cch[2][4];
+    unsigned cpos[2][4];        // AMODE 1: output position of each DMA row, packed t << 22 | h << 11 | w
     int m0 = 0, n0 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // workgroup is persistent: it takes tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or
     // the whole tile count, so vb & 7 stays this workgroup's XCD).
     const int ntiles = ntm * ntn;
-    auto setup = [&](int vb) {
+    auto setup = [&](int vb) __attribute__((always_inline)) {
         constexpr int GM = 8;
         const int wid = xcd_remap(vb, ntiles);
         const int per_group = GM * ntn;
@@ -121,10 +121,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + (pch ^ ((ar >> 1) & 7)) * CE;
                 } else {
                     const int m = min(m0 + ar, M - 1);
-                    cw[h][j] = m % cg.Wo;
-                    ch[h][j] = (m / cg.Wo) % cg.Ho;
-                    ct[h][j] = m / (cg.Wo * cg.Ho);
-                    cch[h][j] = (pch ^ ((ar >> 1) & 7)) * CE;
+                    cpos[h][j] = (unsigned)(m % cg.Wo) | ((unsigned)((m / cg.Wo) % cg.Ho) << 11) |
+                                 ((unsigned)(m / (cg.Wo * cg.Ho)) << 22);
                 }
             }
 #pragma unroll
@@ -134,7 +132,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         }
     };
     const int nk = K / BKE;
-    auto issue_a1 = [&](int h, int j, int t) {
+    auto issue_a1 = [&](int h, int j, int t) __attribute__((always_inline)) {
         t = min(t, nk - 1);
         unsigned char* dst = smem + (t & 1) * BUF_BYTES;
         if (AMODE == 0) {
@@ -144,21 +142,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             const int k0 = t * BKE;
             const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
             const int dt = tap / 9 - 2, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
-            const int tu = max(ct[h][j] + dt, 0);
-            const int hu = min(max(ch[h][j] + dh, 0), cg.Ho - 1);
-            const int wu = min(max(cw[h][j] + dw, 0), cg.Wo - 1);
+            const int tu = max((int)(cpos[h][j] >> 22) + dt, 0);
+            const int hu = min(max((int)((cpos[h][j] >> 11) & 2047) + dh, 0), cg.Ho - 1);
+            const int wu = min(max((int)(cpos[h][j] & 2047) + dw, 0), cg.Wo - 1);
+            // source chunk of this lane: the row's swizzle term is (prow >> 1) | 4 (j & 1)  (rows come 8 per instruction)
+            const int cch = (pch ^ (prow >> 1) ^ ((j & 1) << 2)) * CE;
             const int ts = cg.st ? ((tu + 1) >> 1) : tu;
             const int hs = hu >> cg.sh, ws = wu >> cg.sw;
-            const int64_t off = ((int64_t)(ts * cg.Hi + hs) * cg.Wi + ws) * cg.Cin + c0 + cch[h][j];
+            const int64_t off = ((int64_t)(ts * cg.Hi + hs) * cg.Wi + ws) * cg.Cin + c0 + cch;
             dma16(A + off, dst + arow0[h][j] * 128);
         }
     };
-    auto issue_w1 = [&](int j, int t) {
+    auto issue_w1 = [&](int j, int t) __attribute__((always_inline)) {
         t = min(t, nk - 1);
         dma16(pw[j] + (int64_t)t * BKE, smem + (t & 1) * BUF_BYTES + OP_BYTES + wrow0[j] * 128);
     };
     // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (28 loads per wave)
-    auto prologue = [&] {
+    auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue_a1(0, j, 0);
 #pragma unroll
@@ -201,20 +201,20 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // (ks = g >> 2, mi = 4 p + (g & 3)).
     frag_t wf[2][8], af[4];
 
-    auto rd_a = [&](auto BUF, auto P, auto G) {
+    auto rd_a = [&](auto BUF, auto P, auto G) __attribute__((always_inline)) {
         af[G & 3] = *reinterpret_cast<const frag_t*>(smem + a_rd[BUF][G >> 2] + (P * 64 + (G & 3) * 16) * 128);
     };
-    auto rd_w = [&](auto BUF, auto KS_, auto NI) {
+    auto rd_w = [&](auto BUF, auto KS_, auto NI) __attribute__((always_inline)) {
         wf[KS_][NI] = *reinterpret_cast<const frag_t*>(smem + w_rd[BUF][KS_] + OP_BYTES + (NI * 16) * 128);
     };
     // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0)
-    auto mfma1 = [&](auto P, auto G, auto NI, auto ZC) {
+    auto mfma1 = [&](auto P, auto G, auto NI, auto ZC) __attribute__((always_inline)) {
         constexpr int MI = P * 4 + (G & 3);
         mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0)>(wf[G >> 2][NI], af[G & 3]);
     };
     // what is issued behind MFMA k of group g: at most one LDS read or one LDS-DMA per MFMA gap.
     //   P0(t) issues A-h1(t+1);  P1(t) issues A-h0(t+2) and W(t+2)  (W's fragments sit in registers after P0).
-    auto slot = [&](auto BUF, auto P, int t, auto G, auto K_) {
+    auto slot = [&](auto BUF, auto P, int t, auto G, auto K_) __attribute__((always_inline)) {
         constexpr int g = G, k = K_;
         if constexpr (k == 0) rd_a(BUF, P, ic<g + 2>{});
         if constexpr (P == 0) {
@@ -229,25 +229,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if constexpr (k == 5) issue_w1(2 + g, t + 2);
         }
     };
-    auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+    auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     // relaxed: the 32 output stores of the previous tile may still be in flight behind the loads this phase needs
     // (memory operations retire in order), so the count that guarantees the loads is 16 + 32.
-    auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed) {
+    auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed) __attribute__((always_inline)) {
         if (relaxed) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         fence();
-        if constexpr (P == 0) static_for<8>([&](auto ni) { rd_w(BUF, ic<0>{}, ni); });
+        if constexpr (P == 0) static_for<8>([&](auto ni) __attribute__((always_inline)) { rd_w(BUF, ic<0>{}, ni); });
         rd_a(BUF, P, ic<0>{});
         rd_a(BUF, P, ic<1>{});
         fence();
         if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind
-            static_for<8>([&](auto ni) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}); });
-            static_for<8>([&](auto ni) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}); });
+            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}); });
+            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}); });
         }
         fence();
-        static_for<6>([&](auto g) {
-            static_for<8>([&](auto k) {
+        static_for<6>([&](auto g) __attribute__((always_inline)) {
+            static_for<8>([&](auto k) __attribute__((always_inline)) {
                 mfma1(P, g, k, ZC);
                 fence();
                 slot(BUF, P, t, g, k);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // Stage image: [16 rows][256 B], 16-B chunk index XORed with the row (conflict-free b128 reads, 2-way b64 writes).
     typedef TO Tx8 __attribute__((ext_vector_type(8)));
     Tx8 rpre[2][4];          // EPI 3/4: residual rows (row layout) of two row tiles, a ring filled 2 tiles ahead
-    auto load_resid = [&](int em0, int en0, int mi) {
+    auto load_resid = [&](int em0, int en0, int mi) __attribute__((always_inline)) {
         const int gcol = en0 + wc * 128 + (lane & 15) * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if (gcol < N && m < M) rpre[mi & 1][i] = *reinterpret_cast<const Tx8*>(R + (int64_t)m * ldr + gcol);
         }
     };
-    auto epilogue = [&](int em0, int en0) {
+    auto epilogue = [&](int em0, int en0) __attribute__((always_inline)) {
         unsigned stage_off = 2 * BUF_BYTES + wave * 8192;      // opaque, so that the 4096 of the second stage buffer
         asm volatile("" : "+v"(stage_off));                    // stays an instruction immediate, not 12 more addresses
         unsigned char* stage = smem + stage_off;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         const int lrow = lane >> 4, lchk = lane & 15;
         const int gcol = en0 + wc * 128 + lchk * 8;            // first of this lane's 8 columns in row layout
         const bool col_ok = gcol < N;                          // N % 8 == 0: a chunk is inside or outside
-        static_for<8>([&](auto MI_) {
+        static_for<8>([&](auto MI_) __attribute__((always_inline)) {
             constexpr int mi = MI_;
             unsigned char* sb = stage + (mi & 1) * 4096;
             const int mrow0 = em0 + wr * 128 + mi * 16;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                 if (mi + 2 < 8) load_resid(em0, en0, mi + 2);
             }
             const float as = SCALED ? a_scale[min(mrow0 + fr, M - 1)] : 1.f;
-            static_for<8>([&](auto NI_) {
+            static_for<8>([&](auto NI_) __attribute__((always_inline)) {
                 constexpr int ni = NI_;
                 const int n = nb + ni * 16;
                 unsigned char* sp = sb + fr * 256 + ((((ni * 2) + (fq >> 1)) ^ fr) << 4) + (fq & 1) * 8;
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             }
         }
         fence();
-        static_for<8>([&](auto ni) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}); });
-        static_for<8>([&](auto ni) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}); });
+        static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}); });
+        static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}); });
         fence();
         // every wave is done with the LDS (and the clamped tail loads have landed): the next tile's first loads
         // go out BEFORE this tile's epilogue, whose stores then drain under the next main loop

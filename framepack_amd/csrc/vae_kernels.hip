@@ -9,7 +9,7 @@
 //   * 1x1x1 convolutions and the mid-block attention's linears / QK^T / PV                -> dense fp16 GEMM;
 //   * GroupNorm(32) (+SiLU): deterministic two-stage statistics, then one fused normalise+affine+SiLU pass;
 //   * the mid-block attention's frame-causal softmax over materialised scores (one head of 512 channels).
-#include "gemm_pipeline.h"
+#include "gemm_w4.h"
 
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -24,9 +24,16 @@ extern "C" int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, c
     if (M == 0) return 0;
     const ConvGeom cg{};
     hipStream_t st = (hipStream_t)stream;
+    // 16-byte aligned output (and residual) rows go to the 4-wave kernel (gemm_w4.h), anything else to the 8-wave one
+    const bool wide = ((uintptr_t)c & 15) == 0 && ldc % 8 == 0 &&
+                      (epilogue < 3 || (((uintptr_t)resid & 15) == 0 && ldr % 8 == 0));
     switch (epilogue) {
-        case 0: return launch<f16, 0, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
-        case 4: return launch<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
+        case 0:
+            return wide ? launch_w4<f16, 0, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st)
+                        : launch<f16, 0, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
+        case 4:
+            return wide ? launch_w4<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st)
+                        : launch<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
         default: return (int)hipErrorInvalidValue;      // the VAE uses bias-only and bias+residual
     }
 }
@@ -48,12 +55,16 @@ extern "C" int fp_conv3d_causal_f16(const void* x, const void* w, const void* bi
     cg.Cin = Cin; cg.st = up_t - 1; cg.sh = up_h - 1; cg.sw = up_w - 1;
     const int64_t M64 = (int64_t)cg.To * cg.Ho * cg.Wo;
     FP_REQUIRE(M64 < (1ll << 31) && (int64_t)Ti * Hi * Wi * Cin < (1ll << 40));
+    FP_REQUIRE(cg.To < 1024 && cg.Ho < 2048 && cg.Wo < 2048);          // packed positions in gemm_w4.h
     const int M = (int)M64, N = Cout, K = 27 * Cin;
     FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
     hipStream_t st = (hipStream_t)stream;
+    const bool wide = ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
     if (resid)
-        return launch<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st);
-    return launch<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
+        return wide ? launch_w4<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st)
+                    : launch<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st);
+    return wide ? launch_w4<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st)
+                : launch<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
 }
 
 namespace {

@@ -166,3 +166,32 @@ def test_vae_oracle_framewise_equals_whole_decode_when_short():
     assert tuple(out.shape) == (1, 3, 25, 16, 16)
     mask = VO.frame_causal_mask(2, 3, torch.float32)
     assert mask[:3, 3:].eq(float("-inf")).all() and mask[3:, :].eq(0).all() and mask[:3, :3].eq(0).all()
+
+
+def test_w4_gemm_keeps_compiler_out_of_the_agprs(tmp_path):
+    """gemm_w4.h addresses its 256 accumulator registers (AGPRs) by number from inline asm; the compiler does not
+    know they are live, so it must never use an AGPR itself (it would, as spill space, if a kernel needed more than
+    256 VGPRs).  Disassemble the built code objects and check: inside gemm_w4_kernel the only AGPR traffic is the
+    MFMAs and the epilogue's v_accvgpr_read."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    so = os.path.join(ROOT, "framepack_amd", "libframepack_hip.so")
+    if not (os.path.exists(objdump) and os.path.exists(so)):
+        pytest.skip("needs the ROCm llvm-objdump and the built library")
+    local = shutil.copy(so, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=tmp_path)
+    seen = 0
+    for name in os.listdir(tmp_path):
+        if "gfx950" not in name:
+            continue
+        dis = subprocess.run([objdump, "-d", str(tmp_path / name)], check=True, capture_output=True, text=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            if line.endswith(">:"):
+                cur = line
+                seen += "gemm_w4_kernel" in line
+            elif cur and "gemm_w4_kernel" in cur:
+                assert "v_accvgpr_write" not in line and "v_accvgpr_mov" not in line, (cur, line)
+                assert "scratch_" not in line, (cur, line)
+    assert seen >= 9          # bf16 x 5 epilogues, f16 dense x 2, f16 conv x 2
