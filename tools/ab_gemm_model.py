@@ -1,0 +1,33 @@
+"""Same-process A/B of the two K5 GEMM main loops inside the 13B forward (ms per forward, alternating)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from framepack_amd import lib, synthetic  # noqa: E402
+from framepack_amd.model import HunyuanVideoTransformer3DModelPacked  # noqa: E402
+
+dev = torch.device("cuda:0")
+bf = torch.bfloat16
+with torch.device(dev):
+    model = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_13B).to(bf)
+synthetic.init_synthetic_(dict(model.state_dict()), seed=0, fast_device_rng=True)
+model.eval()
+kw = synthetic.make_inputs(seed=31337, frames_latent=9, height=640, width=640, n_text=256, dtype=bf)
+kw = {k: (v.to(dev) if torch.is_tensor(v) and v.dtype in (bf, torch.bool) else v) for k, v in kw.items()}
+L = lib.load()
+with torch.inference_mode():
+    for _ in range(2):
+        model(return_dict=False, **kw)
+    for rep in range(3):
+        for v in (0, 1):
+            L.fp_debug_gemm_variant(v)
+            model(return_dict=False, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                out = model(return_dict=False, **kw)[0]
+            torch.cuda.synchronize()
+            print(f"rep {rep} variant {v} ({'4-wave' if v else '8-wave'}): {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)
