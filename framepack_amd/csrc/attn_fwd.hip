@@ -15,6 +15,7 @@
 //     V image: [d/32][key][64 B]                                      -> conflict-free tr reads.
 //   * Tails: rows are clamped on load, scores of keys past the segment end are masked to -inf in the
 //     last tile only, query rows past the end are not stored.  Nothing is padded in memory.
+#include <type_traits>
 #include "fp_common.h"
 
 namespace {
@@ -377,6 +378,446 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict
     }
 }
 
+// ======================================================================================================
+// Second-generation sweep: ONE wave per SIMD (4 waves = the same 256 query rows per workgroup), each wave owning
+// 64 query rows (two 32-row blocks rb).  Every K / V^T fragment read from LDS then feeds two MFMAs, and there is no
+// partner wave to hand the matrix pipe to: the wave interleaves its own softmax VALU, LDS reads and LDS-DMA issues
+// one small item per MFMA gap (an MFMA 32x32x16 holds the pipe for 32 cycles, 24 of which take filler issue).
+//
+//   iteration t:   MFMA stream   slots  0..31  O^T += V(t-1)^T . P(t-1)^T      (P of the PREVIOUS tile: no wait on the softmax)
+//                                slots 32..63  S^T(t+1) = K(t+1) . Q^T         -> the AGPR half S(t) is not in
+//                  VALU stream   slots  0..7   S(t): AGPR -> VGPR
+//                                slots  8..13  row max, defer-max test (rescale factors if the max grew by > 2^THR)
+//                                slots 14..63  P(t) = exp2(S(t) * scale - m), row sums, bf16 pack: 32 items of two values,
+//                                              each behind the P.V MFMAs that used the fragment it overwrites
+//                  after slot 63               O *= alpha if the max grew (rare; after V(t-1) is in)
+//   Measured (tools/attn_clock_probe.py and builds with one stream removed): the VECTOR stream is the longer one -
+//   a tile's 64 exp2 (16 cycles each), 64 fma, 64 add, 64 AGPR reads, 36 max, 32 packs and the address / LDS / DMA
+//   issue take ~3 200 cycles against 2 048 cycles of MFMA; with the MFMAs removed a sweep takes 82 % of the full
+//   time, with the softmax removed 67 %.
+//   Accumulators: O^T (4 d-blocks x 2 rb) = a[0:127], S^T (2 key blocks x 2 rb, two tiles) = a[128:255], addressed by number
+//   from inline asm (the compiler cannot keep them in place; see gemm_w4.h).  S(t) (64 VGPRs), P (32), Q (64).
+//   K and V tiles come by LDS-DMA into two rings of three 16 KiB slots (K three tiles ahead, V one); the per-lane
+//   SOURCE address carries the K image's XOR swizzle.  One barrier and one counted vmcnt(8) per tile.
+template <int N> using ic = std::integral_constant<int, N>;
+template <int N, int I = 0, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(ic<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void dma16(const void* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+}
+// a[IDX:IDX+15] += A . B after at most LGKM LDS reads are left in flight (the V^T fragments are read by inline asm -
+// see rd_v - so the compiler does not count them)
+template <int IDX, int LGKM> __device__ __forceinline__ void mfma32_after(const bf16x8& a, const bf16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(IDX), "n"(IDX + 15),
+                 "v"(a), "v"(b), "n"(LGKM));
+}
+// a[IDX:IDX+15] (+)= A . B
+template <int IDX, bool ZERO_C> __device__ __forceinline__ void mfma32(const bf16x8& a, const bf16x8& b) {
+    if constexpr (ZERO_C)
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, 0" ::"n"(IDX), "n"(IDX + 15), "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(IDX), "n"(IDX + 15), "v"(a), "v"(b));
+}
+template <int IDX> __device__ __forceinline__ float agpr_read() {
+    float r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(r) : "n"(IDX));
+    return r;
+}
+template <int IDX> __device__ __forceinline__ void agpr_write(float v) {
+    asm volatile("v_accvgpr_write_b32 a[%0], %1" ::"n"(IDX), "v"(v));
+}
+// (lo, hi) -> packed bf16 pair.  NOT inline asm: gfx950 needs a wait state between a transcendental (the exp2 that
+// produces lo/hi) and a VALU instruction that consumes its result, which the compiler only inserts in front of
+// instructions it knows; as asm, the pack read stale values in some lanes.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2 r = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2);
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// Softmax item i (0..31) of a tile runs behind MFMA 14 + (50 i) / 32; the P^T fragment it completes (k-step i / 8) has
+// been consumed by the previous tile's P.V MFMAs (slots 8 (i/8) .. 8 (i/8) + 7) by then.
+constexpr int w64_item_of_slot(int m) {
+    for (int i = 0; i < 32; ++i)
+        if (14 + (50 * i) / 32 == m) return i;
+    return -1;
+}
+// the k-th (0..7) slot from 14 on without a softmax item carries LDS-DMA instruction k
+constexpr int w64_dma_of_slot(int m) {
+    if (m < 14 || w64_item_of_slot(m) >= 0) return -1;
+    int k = 0;
+    for (int j = 14; j < m; ++j)
+        if (w64_item_of_slot(j) < 0) ++k;
+    return k < 8 ? k : -1;
+}
+
+template <int THR_LOG2>
+__global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                          const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                          int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
+                                                          const int* __restrict__ cu_seqlens, int nseg, int total,
+                                                          int heads, int nqb, float scale_log2e, int nwg_full,
+                                                          int split, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // K ring [3][16 KiB] | V ring [3][16 KiB]
+    constexpr int VRING = 3 * KBUF;
+    constexpr int QBLK = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    asm volatile("" ::: "a0", "a255");          // the kernel descriptor must count the AGPRs the asm below names
+
+    int w, part = 0, nparts = 1;
+    if ((int)blockIdx.x < nwg_full) {
+        w = xcd_remap(blockIdx.x, nwg_full);
+    } else {
+        const int si = blockIdx.x - nwg_full;
+        w = nwg_full + si / split;
+        part = si % split;
+        nparts = split;
+    }
+    const int qb = w % nqb;
+    const int head = (w / nqb) % heads;
+    const int seg = w / (nqb * heads);
+    int seg_lo = 0, seg_hi = total;
+    if (cu_seqlens) {
+        seg_lo = cu_seqlens[seg];
+        seg_hi = cu_seqlens[seg + 1];
+    }
+    const int q0 = seg_lo + qb * QBLK;
+    if (q0 >= seg_hi) return;                   // uniform for the workgroup
+    const int nkv = seg_hi - seg_lo;
+    const int nt_all = (nkv + KVBLK - 1) / KVBLK;
+    const int t0 = (int)((int64_t)nt_all * part / nparts);
+    const int nt = (int)((int64_t)nt_all * (part + 1) / nparts) - t0;
+    float* wsp = ws + (int64_t)((w - nwg_full) * split + part) * WS_FLOATS;
+    if (nt == 0) {
+        for (int i = tid; i < 256; i += 256) {
+            wsp[256 * HD + i] = -INFINITY;
+            wsp[256 * HD + 256 + i] = 0.f;
+        }
+        return;
+    }
+
+    bf16x8 qf[2][8];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        const int qrow = min(q0 + wave * 64 + rb * 32 + r, seg_hi - 1);
+        const bf16* qp = Q + (int64_t)qrow * q_rs + head * HD + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[rb][ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+
+    // ---- LDS-DMA staging.  K: instruction i of this wave = keys wave*16 + 4 i + (0..3), lane = (key, 16-B position);
+    //      the lane fetches the chunk that belongs at its position under the image's XOR.  V: instruction i = d-block
+    //      `wave`, keys 16 i + (0..15), lane = (key, 16-B piece of the 64-B row).
+    const unsigned kcolb[2] = {(unsigned)((head * HD + ((lane & 15) ^ ((lane >> 4) & 15)) * 8) * 2),
+                               (unsigned)((head * HD + ((lane & 15) ^ ((4 + (lane >> 4)) & 15)) * 8) * 2)};
+    // key & 15 of instruction i, lane l: (4 i + (l >> 4)) & 15 -> i = 0..3 gives 0-3, 4-7, 8-11, 12-15
+    const unsigned kxor_i[4] = {0u, 4u, 8u, 12u};
+    (void)kcolb;
+    const unsigned k_step = (unsigned)(KVBLK * k_rs * 2), v_step = (unsigned)(KVBLK * v_rs * 2);
+    const unsigned k_rowmax = (unsigned)((seg_hi - 1) * k_rs * 2), v_rowmax = (unsigned)((seg_hi - 1) * v_rs * 2);
+    const unsigned k_i = (unsigned)(4 * k_rs * 2), v_i = (unsigned)(16 * v_rs * 2);
+    unsigned k_row = (unsigned)((seg_lo + t0 * KVBLK + wave * 16 + (lane >> 4)) * k_rs * 2);     // next K tile to load
+    unsigned v_row = (unsigned)((seg_lo + t0 * KVBLK + (lane >> 2)) * v_rs * 2);                 // next V tile to load
+    const unsigned v_col = (unsigned)((head * HD + wave * 32 + (lane & 3) * 8) * 2);
+    const unsigned k_pos = lane & 15, k_key = lane >> 4;
+    auto issue_k = [&](int i, int slot) __attribute__((always_inline)) {
+        const unsigned col = (unsigned)((head * HD + ((k_pos ^ ((kxor_i[i] + k_key) & 15)) * 8)) * 2);
+        const unsigned off = min(k_row + i * k_i, k_rowmax) + col;
+        dma16(reinterpret_cast<const unsigned char*>(K) + off, smem + slot * KBUF + (wave * 16 + i * 4) * 256);
+    };
+    auto issue_v = [&](int i, int slot) __attribute__((always_inline)) {
+        const unsigned off = min(v_row + i * v_i, v_rowmax) + v_col;
+        dma16(reinterpret_cast<const unsigned char*>(V) + off, smem + VRING + slot * KBUF + wave * (KVBLK * 64) + i * 1024);
+    };
+
+    // ---- fragment read addresses
+    const int i16 = lane & 15;
+    const unsigned v_lane_off = (unsigned)(VRING + (4 * hh + (i16 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
+    const unsigned k_lane_row = (unsigned)(r * 256);
+    const unsigned k_lane_x = (unsigned)(hh ^ (r & 15));       // chunk (2 ks + hh) ^ (r & 15) = (2 ks) ^ k_lane_x
+
+    // ---- state
+    float sv[2][2][16];                          // S(t): [rb][kb][j], key = kb*32 + (j&3) + 8*(j>>2) + 4*hh
+    bf16x8 pf[2][4];                             // P(t-1)/P(t): [rb][k-step]
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[rb][s4][e] = (bf16)0.f;
+    asm volatile(".set fp_i, 0\n.rept 128\nv_accvgpr_write_b32 a[fp_i], 0\n.set fp_i, fp_i + 1\n.endr" ::: "memory");
+
+    auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    auto rd_k = [&](bf16x8& f, unsigned kbase, auto KB, auto KS_) __attribute__((always_inline)) {
+        f = *reinterpret_cast<const bf16x8*>(smem + kbase + KB * 8192 + (((2 * KS_) ^ k_lane_x) << 4));
+    };
+    // Transposing reads as inline asm: behind an LDS-DMA the compiler puts s_waitcnt vmcnt(0) in front of the
+    // ds_read_tr intrinsic (it cannot tell the ring slots apart), which would serialise the loads with the sweep.  The
+    // asm reads are invisible to its lgkmcnt bookkeeping, so their consumers wait explicitly (mfma32_after).
+    auto rd_v = [&](bf16x8& f, unsigned vbase, auto D, auto S4) __attribute__((always_inline)) {
+        union {
+            u32x2 h[2];
+            bf16x8 v;
+        } a;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[0]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4) * 64));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[1]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4 + 8) * 64));
+        f = a.v;
+    };
+
+    // ---- prologue: K(0), K(1), V(0), K(2), V(0) again (so that "all but the last 8 loads" covers what a tile needs)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(i, 0);
+    k_row += k_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(i, 1);
+    k_row += k_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_v(i, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(i, 2);
+    k_row += k_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_v(i, 0);
+    v_row += v_step;
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");      // K(0) landed
+    __builtin_amdgcn_s_barrier();
+    {   // S^T(0) = K(0) . Q^T -> a[128:191]
+        const unsigned kbase = k_lane_row;
+        static_for<8>([&](auto ks) __attribute__((always_inline)) {
+            static_for<2>([&](auto kb) __attribute__((always_inline)) {
+                bf16x8 f;
+                rd_k(f, kbase, kb, ks);
+                static_for<2>([&](auto rb) __attribute__((always_inline)) {
+                    mfma32<128 + (kb * 2 + rb) * 16, (ks == 0)>(f, qf[rb][ks]);
+                });
+            });
+        });
+    }
+
+    int kslot_rd = 1, kslot_wr = 0, vslot_rd = 0, vslot_wr = 1;      // for t = 0
+    // One tile step.  PAR = t & 1: S(t) sits in a[128 + 64 PAR ..], S(t+1) is accumulated into the other half.
+    auto step = [&](int t, auto PAR) __attribute__((always_inline)) {
+        constexpr int SCUR = 128 + 64 * PAR, SNXT = 128 + 64 * (1 - PAR);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_nop 15\ns_nop 7" ::: "memory");               // the last MFMAs of S(t) have retired
+        fence();
+        const unsigned kbase = (unsigned)(kslot_rd * KBUF) + k_lane_row;
+        const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
+        const bool ragged_last = (t0 + t == nt_all - 1) && (nkv & (KVBLK - 1));
+        const int valid = nkv - (t0 + t) * KVBLK;
+        bf16x8 vf[4], kf[4];                                          // fragment rings (three fragments = 6 MFMAs ahead)
+        float mx[2], rs[2] = {0.f, 0.f}, alpha[2] = {1.f, 1.f};
+        bool grow = false;
+        rd_v(vf[0], vbase, ic<0>{}, ic<0>{});
+        rd_v(vf[1], vbase, ic<1>{}, ic<0>{});
+        rd_v(vf[2], vbase, ic<2>{}, ic<0>{});
+        fence();
+        static_for<64>([&](auto M_) __attribute__((always_inline)) {
+            constexpr int m = M_;
+            // ---------------- the MFMA of this slot
+            if constexpr (m < 32) {
+                constexpr int s4 = m >> 3, d = (m >> 1) & 3, rb = m & 1, f = m >> 1;
+                // still in flight behind fragment f: fragments f+1 and f+2 (two reads per V^T fragment, one per K fragment)
+                if constexpr (rb == 0) mfma32_after<(d * 2 + rb) * 16, (f < 14 ? 4 : (f == 14 ? 3 : 2))>(vf[f & 3], pf[rb][s4]);
+                else mfma32<(d * 2 + rb) * 16, false>(vf[f & 3], pf[rb][s4]);
+            } else {
+                constexpr int q = m - 32, ks = q >> 2, kb = (q >> 1) & 1, rb = q & 1, f = q >> 1;
+                mfma32<SNXT + (kb * 2 + rb) * 16, (ks == 0)>(kf[f & 3], qf[rb][ks]);
+            }
+            fence();
+            // ---------------- LDS reads: fragment f+3 while fragment f is multiplied (one fragment per two slots)
+            if constexpr (m < 32 && (m & 1) == 0) {
+                constexpr int f2 = (m >> 1) + 3;
+                if constexpr (f2 < 16) rd_v(vf[f2 & 3], vbase, ic<f2 & 3>{}, ic<(f2 >> 2)>{});
+                else rd_k(kf[f2 & 3], kbase, ic<(f2 - 16) & 1>{}, ic<((f2 - 16) >> 1)>{});
+            }
+            if constexpr (m >= 32 && (m & 1) == 0) {
+                constexpr int f2 = ((m - 32) >> 1) + 3;
+                if constexpr (f2 < 16) rd_k(kf[f2 & 3], kbase, ic<(f2 & 1)>{}, ic<(f2 >> 1)>{});
+            }
+            // ---------------- LDS-DMA: K(t+3) and V(t+1), one instruction in each of the first 8 slots from 14 on that
+            // carry no softmax item
+            if constexpr (w64_dma_of_slot(m) >= 0) {
+                constexpr int i = w64_dma_of_slot(m);
+                if constexpr (i < 4) issue_k(i, kslot_wr);
+                else issue_v(i - 4, vslot_wr);
+            }
+            // ---------------- softmax items.  The vector ALU, not the matrix pipe, is the longer stream of a tile
+            // (64 exp2 at 16 cycles each, plus ~300 plain instructions, plus 8 issue cycles per MFMA), so the items
+            // are spread over ALL 64 MFMA gaps.
+            if constexpr (m < 8) {               // S(t): AGPR -> VGPR, 8 values per slot
+                constexpr int rb = m >> 2, kb = (m >> 1) & 1, j0 = (m & 1) * 8;
+                static_for<8>([&](auto jj) __attribute__((always_inline)) {
+                    sv[rb][kb][j0 + jj] = agpr_read<SCUR + (kb * 2 + rb) * 16 + j0 + jj>();
+                });
+                if constexpr (m == 7) {
+                    if (ragged_last) {
+#pragma unroll
+                        for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                            for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                                for (int j = 0; j < 16; ++j) {
+                                    const int key = kb2 * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+                                    if (key >= valid) sv[rb2][kb2][j] = -INFINITY;
+                                }
+                    }
+                }
+            }
+            if constexpr (m >= 8 && m < 12) {    // row max: 16 values per slot
+                constexpr int i = m - 8, rb = i >> 1, kb = i & 1;
+                float a0 = kb == 0 ? sv[rb][kb][0] : mx[rb];
+                static_for<8>([&](auto jj) __attribute__((always_inline)) {
+                    a0 = fmaxf(fmaxf(a0, sv[rb][kb][2 * jj]), sv[rb][kb][2 * jj + 1]);
+                });
+                mx[rb] = a0;
+                asm volatile("" : "+v"(mx[rb]));
+            }
+            if constexpr (m == 12) {
+                mx[0] = fmaxf(mx[0], other_half(mx[0])) * scale_log2e;
+                mx[1] = fmaxf(mx[1], other_half(mx[1])) * scale_log2e;
+                asm volatile("" : "+v"(mx[0]), "+v"(mx[1]));
+            }
+            if constexpr (m == 13) {
+                grow = !__all((mx[0] - m_run[0] <= (float)THR_LOG2) && (mx[1] - m_run[1] <= (float)THR_LOG2));
+                if (grow) {
+#pragma unroll
+                    for (int rb = 0; rb < 2; ++rb) {
+                        const float m_new = fmaxf(m_run[rb], mx[rb]);
+                        alpha[rb] = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+                        m_run[rb] = m_new;
+                        l_run[rb] *= alpha[rb];
+                    }
+                }
+            }
+            if constexpr (w64_item_of_slot(m) >= 0) {      // P(t): two values per item, in the order the P^T k-steps use them
+                constexpr int i = w64_item_of_slot(m), s4 = i >> 3, rb = (i >> 2) & 1, dw = i & 3;
+                constexpr int kb = s4 >> 1, j = (s4 & 1) * 8 + 2 * dw;
+                const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[rb][kb][j], scale_log2e, -m_run[rb]));
+                const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[rb][kb][j + 1], scale_log2e, -m_run[rb]));
+                rs[rb] += e0;
+                rs[rb] += e1;
+                union {
+                    unsigned u[4];
+                    bf16x8 v;
+                } pk;
+                pk.v = pf[rb][s4];
+                unsigned pw = cvt_pk_bf16(e0, e1);
+                // pin the item to its slot: volatile asm statements keep their order, and the MFMAs are such
+                // statements (left alone, the compiler sinks the whole P computation behind the last MFMA)
+                asm volatile("" : "+v"(pw), "+v"(rs[rb]));
+                pk.u[dw] = pw;
+                pf[rb][s4] = pk.v;
+            }
+            fence();
+        });
+        l_run[0] += rs[0];
+        l_run[1] += rs[1];
+        if (grow) {                                                   // O *= alpha, after V(t-1) has been added
+            asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory");
+            static_for<128>([&](auto I_) __attribute__((always_inline)) {
+                constexpr int i = I_, rb = (i >> 4) & 1;
+                agpr_write<i>(agpr_read<i>() * alpha[rb]);
+            });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        k_row += k_step;
+        v_row += v_step;
+        kslot_wr = kslot_rd;                                          // K(t+4) goes where K(t+1) was
+        kslot_rd = kslot_rd == 2 ? 0 : kslot_rd + 1;
+        vslot_rd = t == 0 ? 0 : (vslot_rd == 2 ? 0 : vslot_rd + 1);
+        vslot_wr = vslot_wr == 2 ? 0 : vslot_wr + 1;
+    };
+    {
+        int t = 0;
+        for (; t + 1 < nt; t += 2) {
+            step(t, ic<0>{});
+            step(t + 1, ic<1>{});
+        }
+        if (t < nt) step(t, ic<0>{});
+    }
+#ifdef FP_W64_DEBUG
+    asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory");
+    const float dbg_o_before0 = agpr_read<0>(), dbg_o_before1 = agpr_read<16>();
+#endif
+    // ---- the last tile's P.V
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    {
+        const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
+        static_for<4>([&](auto s4) __attribute__((always_inline)) {
+            static_for<4>([&](auto d) __attribute__((always_inline)) {
+                bf16x8 f;
+                rd_v(f, vbase, d, s4);
+                static_for<2>([&](auto rb) __attribute__((always_inline)) { mfma32_after<(d * 2 + rb) * 16, 0>(f, pf[rb][s4]); });
+            });
+        });
+    }
+    asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory");
+
+    float l_tot[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = l_run[rb] + other_half(l_run[rb]);
+    if (nparts > 1) {                           // partial sweep: unnormalised O (fp32), running max and sum
+        static_for<2>([&](auto rb) __attribute__((always_inline)) {
+            const int row = wave * 64 + rb * 32 + r;
+            float* op = wsp + row * HD + 4 * hh;
+            static_for<4>([&](auto d) __attribute__((always_inline)) {
+                static_for<4>([&](auto g) __attribute__((always_inline)) {
+                    f32x4 v;
+                    static_for<4>([&](auto j) __attribute__((always_inline)) { v[(int)j] = agpr_read<(d * 2 + rb) * 16 + 4 * g + j>(); });
+                    *reinterpret_cast<f32x4*>(op + d * 32 + g * 8) = v;
+                });
+            });
+            if (hh == 0) {
+                wsp[256 * HD + row] = m_run[rb];
+                wsp[256 * HD + 256 + row] = l_tot[rb];
+            }
+        });
+        return;
+    }
+    static_for<2>([&](auto rb) __attribute__((always_inline)) {
+        const float inv = 1.f / l_tot[rb];
+        const int qrow_real = q0 + wave * 64 + rb * 32 + r;
+#ifdef FP_W64_DEBUG
+        if (qrow_real < seg_hi && hh == 0) {
+            float* dbg = reinterpret_cast<float*>(O + (int64_t)qrow_real * o_rs + head * HD);
+            dbg[0] = l_tot[rb];
+            dbg[1] = m_run[rb];
+            dbg[2] = l_run[rb];
+            dbg[3] = (float)pf[rb][0][0];
+            dbg[4] = (float)pf[rb][0][1];
+            dbg[5] = agpr_read<(0 * 2 + rb) * 16 + 0>();
+            dbg[6] = rb == 0 ? dbg_o_before0 : dbg_o_before1;
+            dbg[7] = (float)pf[rb][1][0];
+        }
+        return;
+#endif
+        if (qrow_real < seg_hi) {
+            bf16* op = O + (int64_t)qrow_real * o_rs + head * HD + 4 * hh;
+            static_for<4>([&](auto d) __attribute__((always_inline)) {
+                static_for<4>([&](auto g) __attribute__((always_inline)) {
+                    bf16x4 v;
+                    static_for<4>([&](auto j) __attribute__((always_inline)) {
+                        v[(int)j] = (bf16)(agpr_read<(d * 2 + rb) * 16 + 4 * g + j>() * inv);
+                    });
+                    *reinterpret_cast<bf16x4*>(op + d * 32 + g * 8) = v;
+                });
+            });
+        }
+    });
+}
+
 // Merge the `split` partial sweeps of each tail item: O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).
 // One workgroup = 16 query rows x 16 chunks of 8 head-dim columns.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, bf16* __restrict__ O,
@@ -434,6 +875,13 @@ int cu_count() {
 
 }  // namespace
 
+static int g_attn_variant = 1;      // 0: 8-wave ping-pong sweep | 1: one wave per SIMD, 64 query rows per wave
+extern "C" int fp_debug_attn_variant(int v) {
+    const int old = g_attn_variant;
+    if (v >= 0) g_attn_variant = v;
+    return old;
+}
+
 // Bytes of device workspace with which fp_attn_fwd_bf16 can split the last round's work items (any shape).
 extern "C" int64_t fp_attn_workspace_bytes(void) { return (int64_t)cu_count() * WS_FLOATS * 4; }
 
@@ -477,12 +925,21 @@ extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
     const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
     // defer-max threshold 2^8: P <= 256 before the bf16 rounding (relative precision unchanged), the O rescale
     // runs only when a row's max grows by more than 8 in the log2 domain
-    auto kern = attn_fwd_kernel<8>;
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KBUF);
-    if (e != hipSuccess) return (int)e;
-    kern<<<dim3((unsigned)grid), dim3(512), 4 * KBUF, (hipStream_t)stream>>>(
-        (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
-        o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
+    if (g_attn_variant == 1) {
+        auto kern = attn_w64_kernel<8>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KBUF);
+        if (e != hipSuccess) return (int)e;
+        kern<<<dim3((unsigned)grid), dim3(256), 6 * KBUF, (hipStream_t)stream>>>(
+            (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
+            o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
+    } else {
+        auto kern = attn_fwd_kernel<8>;
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KBUF);
+        if (e != hipSuccess) return (int)e;
+        kern<<<dim3((unsigned)grid), dim3(512), 4 * KBUF, (hipStream_t)stream>>>(
+            (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
+            o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
+    }
     FP_CHECK_LAUNCH();
     if (nwg_full < nwg)
         attn_combine_kernel<<<dim3((unsigned)((nwg - nwg_full) * 16)), dim3(256), 0, (hipStream_t)stream>>>(

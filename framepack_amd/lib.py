@@ -26,6 +26,8 @@ SIGNATURES = {
     "fp_rel_l1_bf16": [P, P, L, P, P],
     "fp_gemm_bf16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_gemm_f16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
+    "fp_debug_gemm_variant": [I],
+    "fp_debug_attn_variant": [I],
     "fp_quantize_rows_fp8": [P, L, I, P, L, I, P, L, P, I, P],
     "fp_gemm_fp8_bf16": [P, L, P, P, L, P, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_conv3d_causal_f16": [P, P, P, P, I, I, I, I, I, I, I, I, P, P],

@@ -141,6 +141,13 @@ int fp_groupnorm_apply_f16(const void* x, void* y, int64_t rows, int C, int grou
 int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int tokens_per_frame, float scale,
                                void* stream);
 
+/* ---- diagnostics (no counterpart in the reference) --------------------------------------------------------
+ * Select the kernel generation used by fp_gemm_bf16 / fp_attn_fwd_bf16 for same-process A/B measurements
+ * (tools/ab_model.py): 0 = first generation (8 waves per workgroup), 1 = second (one wave per SIMD; default).
+ * v < 0 only queries.  Returns the previous value.  Process-wide, not thread-safe. */
+int fp_debug_gemm_variant(int v);
+int fp_debug_attn_variant(int v);
+
 #ifdef __cplusplus
 }
 #endif

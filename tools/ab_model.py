@@ -1,4 +1,5 @@
-"""Same-process A/B of the two K5 GEMM main loops inside the 13B forward (ms per forward, alternating)."""
+"""Same-process A/B of kernel generations inside the 13B forward (ms per forward, alternating).
+usage: ab_gemm_model.py [gemm|attn]"""
 import os
 import sys
 import time
@@ -23,11 +24,11 @@ with torch.inference_mode():
         model(return_dict=False, **kw)
     for rep in range(3):
         for v in (0, 1):
-            L.fp_debug_gemm_variant(v)
+            (L.fp_debug_attn_variant if (len(sys.argv) > 1 and sys.argv[1] == "attn") else L.fp_debug_gemm_variant)(v)
             model(return_dict=False, **kw)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3):
                 out = model(return_dict=False, **kw)[0]
             torch.cuda.synchronize()
-            print(f"rep {rep} variant {v} ({'4-wave' if v else '8-wave'}): {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)
+            print(f"rep {rep} {sys.argv[1] if len(sys.argv) > 1 else 'gemm'} variant {v} ({'4-wave' if v else '8-wave'}): {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)
