@@ -277,6 +277,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
 
         self._rope_cache = RopeCache(rope_axes_dim, rope_theta)
         self._packed = None            # fused weight buffers, built lazily (see _pack)
+        self._invariant = {}           # step-invariant results keyed by the identity of their inputs (see _cached)
         self._ws = {}                  # activation workspaces keyed by (S, device)
         self.taps = None               # optional dict: per-block outputs for parity tests
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
@@ -318,6 +319,30 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         if self.heads % self.sp_world != 0:
             raise ValueError(f"{self.heads} heads do not divide over {self.sp_world} ranks")
         self._ws = {}
+
+    def _cached(self, slot: str, src: torch.Tensor, fn):
+        """Cross-step cache of work that depends only on a tensor the caller passes unchanged for every step of a
+        section: the clean-latent patch embeddings and the image projection, which the
+        reference recomputes 25 times (`ref :841-866, :917-924`; the clean latents even arrive as fp32 CPU tensors and
+        are re-uploaded every step).  The key is the tensor's identity (storage address, shape, dtype, in-place
+        version counter): a different or modified tensor recomputes.  Tensors made under torch.inference_mode (how the
+        reference's worker runs) carry no version counter; for those a CPU tensor is fingerprinted by a strided sample
+        of its values, a GPU tensor by identity alone (the worker builds fresh tensors per section and never writes
+        into them).  One entry per slot."""
+        if not src.is_inference():
+            stamp = src._version
+        elif src.device.type == "cpu":
+            flat = src.reshape(-1)
+            stamp = tuple(flat[:: max(1, flat.numel() // 61)].double().tolist())
+        else:
+            stamp = None
+        key = (src.data_ptr(), tuple(src.shape), src.dtype, str(src.device), stamp)
+        hit = self._invariant.get(slot)
+        if hit is not None and hit[0] == key and hit[1] is src:
+            return hit[2]
+        val = fn()
+        self._invariant[slot] = (key, src, val)       # holding `src` keeps its address from being reused
+        return val
 
     def enable_fp8_compute(self, enable: bool = True):
         """Run the linears of the double/single blocks on the gfx950 fp8 MFMA (K6): weights held as e4m3 with a
@@ -369,11 +394,13 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
     # ---- weight fusion ---------------------------------------------------------------------
     def _apply(self, fn, *a, **k):                      # .to() / .cuda() / .half(): fused buffers go stale
         self._packed = None
+        self._invariant = {}
         self._ws = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed = None
+        self._invariant = {}
         return super().load_state_dict(*a, **k)
 
     @staticmethod
@@ -479,7 +506,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
     # ---- packing of the input streams (ref :822-879) ----------------------------------------
     def _embed_stream(self, x, kernel, w, b, out):
         rows = patch_rows(pad_to_multiple(x, kernel), kernel)
-        ops.gemm(rows, w, b, out=out)
+        return ops.gemm(rows, w, b, out=out)
 
     def process_input_hidden_states(self, latents, latent_indices=None, clean_latents=None, clean_latent_indices=None,
                                     clean_latents_2x=None, clean_latent_2x_indices=None, clean_latents_4x=None,
@@ -510,12 +537,13 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             out = torch.empty((Si, self.inner_dim), dtype=BF16, device=latents.device)
         r0 = 0
         for (x, k, wi, _, _), n in zip(streams, counts):
-            x = x.to(latents)                                           # ref :841, 852, 866
             if wi < 0:                                                  # Conv3d floors a ragged edge (no padding)
-                x = x[:, :, :t * pt, :h * p, :w * p]
+                x = x.to(latents)[:, :, :t * pt, :h * p, :w * p]
                 self._embed_stream(x, k, P.w_xe, P.b_xe, out[r0:r0 + n])
-            else:
-                self._embed_stream(x, k, P.w_ce[wi], P.b_ce[wi], out[r0:r0 + n])
+            else:                                                       # clean streams: the same tensors all section long
+                emb = self._cached(f"clean{wi}", x, lambda x=x, k=k, wi=wi: self._embed_stream(
+                    x.to(latents), k, P.w_ce[wi], P.b_ce[wi], None))    # ref :841, 852, 866
+                out[r0:r0 + n].copy_(emb)
             r0 += n
         rope = self._rope_cache.get([(i, pool) for _, _, _, i, pool in streams], h, w, latents.device)
         return out[:Si].unsqueeze(0), rope
@@ -623,7 +651,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         mask = encoder_attention_mask
         if self.image_projection is not None:
             assert image_embeddings is not None, "You must use image embeddings!"
-            extra = self.image_projection(image_embeddings)
+            extra = self._cached("image_projection", image_embeddings,
+                                 lambda: self.image_projection(image_embeddings))
             ctx = torch.cat([extra, ctx], dim=1)                     # image tokens before text (ref :922-923)
             mask = torch.cat([torch.ones((B, extra.shape[1]), dtype=mask.dtype, device=mask.device), mask], dim=1)
 

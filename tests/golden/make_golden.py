@@ -10,6 +10,8 @@ What is pinned by what:
                                  stay "parity unpinned").
   * sampler.npz              <- diffusers_helper/k_diffusion/{uni_pc_fm,wrapper}.py (import as is).
   * fp8.npz                  <- utils/fp8_optimization_utils.py (imports as is).
+  * lora.npz                 <- utils/lora_utils.py (imports as is): the three LoRA layouts merged into seeded
+                                 state dicts (inputs rebuilt in the test by tests/lora_cases.py).
 Inputs are regenerated in the tests from the same seeds (framepack_amd/synthetic.py,
 oracle.dit_oracle.synth_params); only outputs (sub-sampled where large) are stored.
 """
@@ -241,8 +243,35 @@ def gen_fp8():
     print("fp8.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- lora
+def gen_lora():
+    import tempfile
+    from safetensors.torch import save_file
+    from utils import lora_utils as ref_lora
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import lora_cases
+    out = {}
+    for name in lora_cases.CASES:
+        sd, lora, mult = lora_cases.build(name)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, name + ".safetensors")
+            save_file({k: v.contiguous() for k, v in lora.items()}, path)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                merged = ref_lora.merge_lora_to_state_dict(dict(sd), path, mult, torch.device("cpu"))
+        for k, v in merged.items():
+            changed = not (v.dtype == sd[k].dtype and torch.equal(v, sd[k]))
+            out[f"{name}/{k}/changed"] = np.array([int(changed)])
+            out[f"{name}/{k}/dtype"] = np.array([str(v.dtype)])
+            if changed:
+                out[f"{name}/{k}/sample"] = lora_cases.sample(v).numpy()
+                out[f"{name}/{k}/sum"] = np.array([v.double().sum().item(), v.double().abs().sum().item()])
+    np.savez_compressed(os.path.join(HERE, "lora.npz"), **out)
+    print("lora.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
     gen_rope()
     gen_sampler()
     gen_fp8()
+    gen_lora()
     gen_dit_tiny()

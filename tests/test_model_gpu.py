@@ -207,6 +207,44 @@ def test_fp8_compute_mode_uses_reference_checkpoint_bytes_and_scales():
     assert 1e-3 < rel_l2(w8a8, w8a16) < 0.12
 
 
+def test_cross_step_cache_of_clean_embeds_and_image_projection(tiny):
+    """clean-latent patch embeddings and the image projection are computed once per section (the
+    caller passes the same tensors every step) and recomputed when a tensor is replaced or modified in place."""
+    m, P32 = tiny
+    cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
+    kw = synthetic.make_inputs(dtype=BF, **CASES["config1"])
+    dkw = to_dev(kw)                               # clean latents stay fp32 CPU tensors, as the worker passes them
+    m._invariant = {}
+    calls = {"n": 0}
+    real = m._embed_stream
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    m._embed_stream = counting
+    try:
+        a = m(return_dict=False, **dkw)[0]
+        first = calls["n"]                         # noisy + 3 clean streams
+        b = m(return_dict=False, **dkw)[0]
+        assert calls["n"] - first == 1             # second step: only the noisy latents are embedded
+        assert torch.equal(a, b)
+        assert rel_l2(a, O.dit_forward(P32, cfg, **to_f32(kw))) < TOL
+        # in-place modification bumps the version counter -> recompute, and the result follows the new values
+        kw["clean_latents"].mul_(0.5)
+        c = m(return_dict=False, **dkw)[0]
+        assert calls["n"] - first == 3
+        assert not torch.equal(a, c)
+        assert rel_l2(c, O.dit_forward(P32, cfg, **to_f32(kw))) < TOL
+        # a different tensor object with the same values -> recompute, same result
+        dkw2 = dict(dkw, clean_latents_2x=dkw["clean_latents_2x"].clone())
+        d = m(return_dict=False, **dkw2)[0]
+        assert calls["n"] - first == 5
+        assert torch.equal(c, d)
+    finally:
+        m._embed_stream = real
+        m._invariant = {}
+
+
 def test_full_width_blocks_match_oracle():
     """13B width (24 heads x 128, d = 3072, mlp 12288), 1 double + 1 single block, 320x320x33f section
     (S = 5 585 tokens): per-block rel-L2 against the fp32 oracle."""
