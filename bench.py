@@ -200,7 +200,7 @@ def main():
     if args.config == "13b" and world == 1 and rows == 19385 and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = round(json.load(f)["traffic_bytes_per_launch"])
-    roofline = {"kernel": "attn_fwd_kernel<8> (K1 flash attention, bf16 MFMA 32x32x16, ping-pong schedule)", "bound": "mfma",
+    roofline = {"kernel": "attn_w64_kernel<8> (K1 flash attention, bf16 MFMA 32x32x16, one wave per SIMD)", "bound": "mfma",
                 "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_BF16_PEAK, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC, profiles/r1_e_attn_hbm_traffic.json; algorithmic 476 MB)",
