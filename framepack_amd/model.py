@@ -281,6 +281,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ws = {}                  # activation workspaces keyed by (S, device)
         self.taps = None               # optional dict: per-block outputs for parity tests
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
+        self._sp_total = 0
         self.fp8_compute = False       # block linears on the fp8 MFMA (enable_fp8_compute)
 
     # ---- reference API ---------------------------------------------------------------------
@@ -363,7 +364,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             ops.attention(q, k, v, self.heads, out=q)
         else:
             from .ulysses import ulysses_attention
-            ulysses_attention(q, k, v, n_img, self.heads, self.head_dim,
+            ulysses_attention(q, k, v, self._sp_total, self.heads, self.head_dim,
                               lambda jq, jk, jv, h, o: ops.attention(jq, jk, jv, h, out=o), self.sp_group, out=q)
 
     @property
@@ -675,18 +676,25 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                                                        clean_latents_4x, clean_latent_4x_indices, out=ws.X[:n_img])
             rope = rope[0]
         else:
-            # sequence parallel: this rank keeps image rows [lo, hi) (+ all text rows, replicated)
-            from .ulysses import shard_bounds
-            lo, hi = shard_bounds(n_img, self.sp_world, self.sp_rank)
-            Si = hi - lo
-            S = Si + text_len
+            # sequence parallel: this rank keeps rows [g0, g0 + valid) of the packed sequence [image | text]; the
+            # rest of its n rows is padding (computed, never attended to).  Si = its image rows, the others are text.
+            from .ulysses import row_shard
+            S_total = n_img + text_len
+            n_loc, g0, valid = row_shard(S_total, self.sp_world, self.sp_rank)
+            lo = min(g0, n_img)
+            Si = min(g0 + valid, n_img) - lo
+            t0 = max(g0, n_img) - n_img
+            tvalid = valid - Si
+            self._sp_total = S_total
+            S = n_loc
             ws = self._workspace(S, dev)
             full, rope = self.process_input_hidden_states(hidden_states, latent_indices, clean_latents,
                                                           clean_latent_indices, clean_latents_2x,
                                                           clean_latent_2x_indices, clean_latents_4x,
                                                           clean_latent_4x_indices)
-            ws.X[:Si].copy_(full[0, lo:hi])
-            rope = rope[0, lo:hi].contiguous()
+            ws.X[:Si].copy_(full[0, lo:lo + Si])
+            rope = rope[0, lo:lo + Si].contiguous()
+            ctx = torch.cat([ctx[:, t0:t0 + tvalid], ctx.new_zeros((1, n_loc - valid, ctx.shape[2]))], dim=1)
         ws.X[Si:].copy_(ctx[0])
 
         # all AdaLN modulations of this step: one GEMV over the concatenated modulation weights
@@ -706,12 +714,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                 self.accumulated_rel_l1_distance = 0
                 self.cache_misses += 1
             else:
-                acc_t = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc)
+                acc_t = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc) if Si > 0 else ws.acc.zero_()
                 if self.sp_world > 1:                       # identical decision on every rank
                     import torch.distributed as dist
                     dist.all_reduce(acc_t, group=self.sp_group)
                 acc = acc_t.tolist()                                           # host sync (ref :958)
-                n = modulated.numel() * self.sp_world
+                n = n_img * d                               # elements over all ranks
                 curr = (acc[0] / n) / (acc[1] / n + 1e-8)
                 self.accumulated_rel_l1_distance += self.teacache_rescale_func(curr)
                 should_calc = self.accumulated_rel_l1_distance >= self.rel_l1_thresh
@@ -738,10 +746,13 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
 
         # output head (ref :1044-1057): norm_out is token-wise, so slice first; (scale, shift) order of :501
         scale, shift = mods[-2 * d:-d], mods[-d:]
-        # rows of this rank that belong to the noisy-latent tokens (the last ctx_len rows of the image sequence)
-        first = max(0, (n_img - ctx_len) - lo)
-        head_in = ops.layernorm_modulate(ws.X[first:Si], scale, shift, out=ws.N[:Si - first]) if Si > first else \
-            ws.N[:0]
+        if self.sp_world == 1:
+            # the noisy-latent tokens are the last ctx_len rows of the image sequence
+            first = n_img - ctx_len
+            head_in = ops.layernorm_modulate(ws.X[first:Si], scale, shift, out=ws.N[:Si - first])
+        else:
+            # every rank runs the (tiny) head over all of its rows; the noisy-latent rows are cut out of the gather
+            head_in = ops.layernorm_modulate(ws.X, scale, shift, out=ws.N)
         if self.high_quality_fp32_output_for_inference:
             if self.proj_out.weight.dtype != torch.float32:
                 self.proj_out.to(dtype=torch.float32)
@@ -751,10 +762,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             out = ops.gemm(head_in, self.proj_out.weight.detach(), self.proj_out.bias.detach())
         if self.sp_world > 1:
             from .ulysses import gather_rows
-            n_loc = n_img // self.sp_world
-            padded = out.new_zeros((n_loc, out.shape[1]))
-            padded[n_loc - out.shape[0]:] = out
-            out = gather_rows(padded, self.sp_group)[n_img - ctx_len:]
+            out = gather_rows(out, self.sp_group)[n_img - ctx_len:n_img]
         if self.taps is not None:
             self.taps["head"] = out
         out = unpatchify(out, B, t2, h2, w2, self.config["out_channels"], p_t, p)

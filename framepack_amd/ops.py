@@ -55,6 +55,8 @@ def layernorm_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor
     scale = scale.reshape(-1).contiguous()
     shift = shift.reshape(-1).contiguous()
     assert scale.numel() == cols and shift.numel() == cols and scale.dtype == BF16 and shift.dtype == BF16
+    if rows == 0:                                   # an empty row range (a sequence-parallel rank without text rows)
+        return out
     _lib.check(_lib.load().fp_layernorm_modulate_bf16(x2.data_ptr(), xs, scale.data_ptr(), shift.data_ptr(),
                                                       o2.data_ptr(), os_, rows, cols, eps, _stream(x)),
                "fp_layernorm_modulate_bf16")
@@ -69,6 +71,8 @@ def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate: torch.Tensor) -> torc
     gate = gate.reshape(-1).contiguous()
     assert (yr, yc) == (rows, cols) and gate.numel() == cols
     assert x.dtype == BF16 and y.dtype == BF16 and gate.dtype == BF16
+    if rows == 0:
+        return x
     _lib.check(_lib.load().fp_gate_residual_bf16(x2.data_ptr(), xs, y2.data_ptr(), ys, gate.data_ptr(), rows, cols,
                                                  _stream(x)), "fp_gate_residual_bf16")
     return x
@@ -196,6 +200,8 @@ def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
         out = torch.empty((M, N), dtype=dt, device=a.device)
     o_, Mo, No, ldc = _rows2d(out)
     assert (Mo, No) == (M, N) and out.dtype == dt
+    if M == 0:                                      # an empty row range (a sequence-parallel rank without text rows)
+        return out
     ldr = 0
     rptr, gptr = None, None
     if epilogue in (EPI_GATE_RESIDUAL, EPI_RESIDUAL):
@@ -238,6 +244,10 @@ def quantize_rows_fp8(x: torch.Tensor, x2: Optional[torch.Tensor] = None, out: O
     _dev(x, x2, out, scale)
     x_, M, K1, ld1 = _rows2d(x)
     assert x.dtype == BF16
+    if M == 0:
+        K2 = 0 if x2 is None else x2.shape[-1]
+        return (torch.empty((0, K1 + K2), dtype=FP8, device=x.device) if out is None else out,
+                torch.empty((0,), dtype=torch.float32, device=x.device) if scale is None else scale)
     K2, ld2, x2p = 0, 0, None
     if x2 is not None:
         x2_, M2, K2, ld2 = _rows2d(x2)
@@ -270,6 +280,8 @@ def gemm_fp8(a_q: torch.Tensor, a_scale: torch.Tensor, w_q: torch.Tensor, w_scal
         out = torch.empty((M, N), dtype=BF16, device=a_q.device)
     o_, Mo, No, ldc = _rows2d(out)
     assert (Mo, No) == (M, N) and out.dtype == BF16
+    if M == 0:
+        return out
     ldr, rptr, gptr = 0, None, None
     if epilogue in (EPI_GATE_RESIDUAL, EPI_RESIDUAL):
         r_, Mr, Nr, ldr = _rows2d(resid)

@@ -1,15 +1,16 @@
 """Ulysses-style sequence parallelism for the joint attention of the packed DiT (RCCL all-to-all over xGMI).
 
 New design (the reference is single-GPU: SURVEY.md 2a); the contract is "same result as 1 GPU".
-  * the IMAGE token rows are sharded evenly over the P ranks (n = Si / P rows each); every token-wise op
-    (LayerNorm+modulate, GEMMs, RMSNorm+RoPE, gated residual) runs on the local rows only;
-  * the TEXT rows (<= 985, ~5 % of the sequence, data-dependent length) are replicated: every rank computes
-    them for all heads, so their length never has to be split;
-  * attention needs all tokens of a head: one all-to-all turns [n rows, all 24 heads] into
-    [all Si rows, 24/P heads] for q, k and v together (one exchange, 3*d*n elements per rank), the local
-    rank's head group of the replicated text rows is appended, the K1 kernel runs on 24/P heads, and the
-    inverse all-to-all returns [n rows, all heads]; the text rows of the output ride in the same exchange
-    (every peer gets them), so no second collective is needed.
+  * the PACKED sequence [image rows | image-projection + text rows] (S rows) is cut into P equal runs of
+    n = ceil(S / P) rows: rank r holds rows [r n, (r+1) n); the run that crosses the image/text boundary simply holds
+    both kinds, and the rows past S (on the last rank(s)) are padding - computed, never attended to, never returned.
+    Every token-wise op (LayerNorm+modulate, GEMMs, RMSNorm+RoPE, gated residual) runs on the n local rows: 1/P of
+    the single-GPU work for any S and P (no divisibility condition on the image token count; the first version
+    replicated the text rows: +35 % GEMM rows per rank at P = 8);
+  * attention needs all tokens of a head: one all-to-all turns [n rows, all 24 heads] into [P n rows, 24/P heads]
+    for q, k and v together (one exchange, 3 d n elements per rank); rank order = sequence order, so the received
+    buffer IS the packed sequence with the padding at its end and the K1 kernel runs on its first S rows; the
+    inverse all-to-all returns [n rows, all heads].
 xGMI is point-to-point: an all-to-all sends a distinct slice to each of the 7 peers and uses all links at once.
 
 The exchange is written against torch.distributed so that it runs on RCCL (backend "nccl") on the GPUs and on
@@ -23,56 +24,60 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(n_rows: int, world: int, rank: int):
-    """Even row split; n_rows must be a multiple of world (the caller pads the image stream otherwise)."""
-    if n_rows % world != 0:
-        raise ValueError(f"image token count {n_rows} is not a multiple of the sequence-parallel degree {world}")
-    n = n_rows // world
-    return rank * n, (rank + 1) * n
+def row_shard(n_rows: int, world: int, rank: int):
+    """(rows per rank n, first global row, valid rows) of this rank's run of an n_rows-long sequence."""
+    n = -(-n_rows // world) if n_rows else 0
+    lo = min(rank * n, n_rows)
+    return n, lo, min(n, n_rows - lo)
 
 
-def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_img: int, heads: int, head_dim: int,
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group) -> None:
+    """all_to_all_single; gloo has no GPU all-to-all, so GPU tensors on a gloo group (the 2-process test on one GPU)
+    are staged through host memory.  RCCL takes the direct path."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
+def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total: int, heads: int, head_dim: int,
                       attn_fn: Callable, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q, k, v: [n_img + n_txt, heads*head_dim] views (row-strided ok) holding this rank's image rows followed by
-    the replicated text rows.  Returns / fills `out` (same shape; may be q) with the attention output of the
-    local image rows and of all text rows, for all heads.
+    """q, k, v: [n, heads*head_dim] views (row-strided ok) holding this rank's run of the packed sequence (row_shard;
+    padding rows included).  n_total = S, the valid rows over all ranks.  Returns / fills `out` (same shape; may be q)
+    with the attention output of the local rows for all heads (padding rows: zeros).
 
-    attn_fn(q, k, v, heads_local, out) -> out   over [Si + n_txt, heads_local*head_dim] views."""
+    attn_fn(q, k, v, heads_local, out) -> out   over [S, heads_local*head_dim] views."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     if heads % world != 0:
         raise ValueError(f"{heads} heads do not divide over {world} ranks")
     hl = heads // world
     hw = hl * head_dim
-    rows = q.shape[0]
-    n_txt = rows - n_img
-    Si = n_img * world
+    n = q.shape[0]
+    if n != row_shard(n_total, world, 0)[0]:
+        raise ValueError(f"{n} local rows do not match {n_total} rows over {world} ranks")
     dev, dt = q.device, q.dtype
 
-    # ---- forward exchange: [n_img, P, (q|k|v), hw] -> per-peer contiguous [P, n_img, 3*hw]
-    send = torch.stack([q[:n_img].reshape(n_img, world, hw), k[:n_img].reshape(n_img, world, hw),
-                        v[:n_img].reshape(n_img, world, hw)], dim=2).permute(1, 0, 2, 3).contiguous()
-    joint = torch.empty((Si + n_txt, 3 * hw), dtype=dt, device=dev)
-    dist.all_to_all_single(joint[:Si], send.view(world * n_img, 3 * hw), group=group)
-    if n_txt:
-        c0 = rank * hw
-        joint[Si:, :hw] = q[n_img:, c0:c0 + hw]
-        joint[Si:, hw:2 * hw] = k[n_img:, c0:c0 + hw]
-        joint[Si:, 2 * hw:] = v[n_img:, c0:c0 + hw]
+    # ---- forward exchange: [n, P, (q|k|v), hw] -> per-peer contiguous [P, n, 3*hw]; received = the sequence in order
+    send = torch.stack([q.reshape(n, world, hw), k.reshape(n, world, hw), v.reshape(n, world, hw)],
+                       dim=2).permute(1, 0, 2, 3).contiguous()
+    joint = torch.empty((world * n, 3 * hw), dtype=dt, device=dev)
+    _all_to_all(joint, send.view(world * n, 3 * hw), group)
 
-    # ---- attention over all tokens, local head group (output over q)
-    jq, jk, jv = joint[:, :hw], joint[:, hw:2 * hw], joint[:, 2 * hw:]
-    o = attn_fn(jq, jk, jv, hl, jq)
+    # ---- attention over the valid tokens, local head group (output over q)
+    S = n_total
+    o = attn_fn(joint[:S, :hw], joint[:S, hw:2 * hw], joint[:S, 2 * hw:], hl, joint[:S, :hw])
 
-    # ---- inverse exchange: to peer p its image rows (+ all text rows), my head group
-    back = torch.empty((world, n_img + n_txt, hw), dtype=dt, device=dev)
-    back[:, :n_img] = o[:Si].reshape(world, n_img, hw)
-    if n_txt:
-        back[:, n_img:] = o[Si:].unsqueeze(0)
-    recv = torch.empty_like(back)
-    dist.all_to_all_single(recv.view(world * (n_img + n_txt), hw), back.view(world * (n_img + n_txt), hw), group=group)
+    # ---- inverse exchange: to peer p its rows, my head group
+    back = torch.empty((world * n, hw), dtype=dt, device=dev)
+    back[:S] = o
+    if S < world * n:
+        back[S:].zero_()
+    recv = torch.empty((world, n, hw), dtype=dt, device=dev)
+    _all_to_all(recv.view(world * n, hw), back, group)
     if out is None:
-        out = torch.empty((rows, heads * head_dim), dtype=dt, device=dev)
+        out = torch.empty((n, heads * head_dim), dtype=dt, device=dev)
     # recv[p] = head group p of my rows  ->  out[:, p*hw:(p+1)*hw]
     out_v = out.unflatten(1, (world, hw)) if out.is_contiguous() else None
     if out_v is not None:
@@ -87,5 +92,10 @@ def gather_rows(x: torch.Tensor, group=None) -> torch.Tensor:
     """all-gather equal row shards [n, c] -> [P*n, c] in rank order (output head, TeaCache residuals)."""
     world = dist.get_world_size(group)
     out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    if x.is_cuda and dist.get_backend(group) == "gloo":          # see _all_to_all
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, x.contiguous().cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, x.contiguous(), group=group)
     return out

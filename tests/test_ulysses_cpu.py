@@ -1,7 +1,7 @@
 """Sequence-parallel exchange (framepack_amd.ulysses) on world_size-2 and -4 gloo groups on the CPU:
 sharded attention == unsharded attention.  The attention itself is injected (the oracle's SDPA here; the
-product injects the HIP kernel), so this covers the all-to-all index math, the replicated-text handling
-and the row gathers by construction."""
+product injects the HIP kernel), so this covers the all-to-all index math, the padding rows at the end of the
+sequence, and the row gathers by construction."""
 import os
 import socket
 
@@ -31,18 +31,19 @@ def _worker(rank, world, port, n_img_total, n_txt, heads, strided, ret):
         q, k, v = (torch.randn(n_img_total + n_txt, d, generator=g) for _ in range(3))
         full = torch.empty_like(q)
         _attn(q, k, v, heads, full)
-        lo, hi = ulysses.shard_bounds(n_img_total, world, rank)
-        rows = torch.cat([torch.arange(lo, hi), torch.arange(n_img_total, n_img_total + n_txt)])
+        S = n_img_total + n_txt
+        n, lo, valid = ulysses.row_shard(S, world, rank)
+        pad = torch.full((n - valid, d), float("nan"))          # padding rows: whatever they hold must not matter
+        lq0, lk0, lv0 = (torch.cat([t[lo:lo + valid], pad]) for t in (q, k, v))
         if strided:                                   # q|k|v as column ranges of one buffer, output over q
-            buf = torch.cat([q[rows], k[rows], v[rows], torch.zeros(len(rows), 64)], dim=1)
+            buf = torch.cat([lq0, lk0, lv0, torch.zeros(n, 64)], dim=1)
             lq, lk, lv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
-            got = ulysses.ulysses_attention(lq, lk, lv, hi - lo, heads, 128, _attn, out=lq)
+            got = ulysses.ulysses_attention(lq, lk, lv, S, heads, 128, _attn, out=lq)
         else:
-            got = ulysses.ulysses_attention(q[rows].contiguous(), k[rows].contiguous(), v[rows].contiguous(),
-                                            hi - lo, heads, 128, _attn)
-        err = (got - full[rows]).abs().max().item()
-        gathered = ulysses.gather_rows(got[:hi - lo].contiguous())
-        err2 = (gathered - full[:n_img_total]).abs().max().item()
+            got = ulysses.ulysses_attention(lq0.contiguous(), lk0.contiguous(), lv0.contiguous(), S, heads, 128, _attn)
+        err = (got[:valid] - full[lo:lo + valid]).abs().max().item() if valid else 0.0
+        gathered = ulysses.gather_rows(got.contiguous())[:S]
+        err2 = (gathered - full).abs().max().item()
         ret[rank] = max(err, err2)
     finally:
         dist.destroy_process_group()
@@ -55,7 +56,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,n_img,n_txt,heads,strided", [(2, 64, 9, 2, False), (2, 50, 0, 4, True),
-                                                           (4, 40, 7, 4, True)])
+                                                           (4, 40, 7, 4, True), (4, 41, 2, 4, False),
+                                                           (2, 63, 10, 2, True), (4, 2, 1, 4, False)])
 def test_ulysses_attention_equals_unsharded(world, n_img, n_txt, heads, strided):
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), n_img, n_txt, heads, strided, ret), nprocs=world, join=True)
@@ -63,7 +65,9 @@ def test_ulysses_attention_equals_unsharded(world, n_img, n_txt, heads, strided)
     assert max(ret.values()) < 1e-5
 
 
-def test_shard_bounds_rejects_ragged_split():
-    with pytest.raises(ValueError):
-        ulysses.shard_bounds(10, 4, 0)
-    assert ulysses.shard_bounds(18400, 8, 7) == (16100, 18400)
+def test_row_shard():
+    assert ulysses.row_shard(19385, 8, 0) == (2424, 0, 2424)
+    assert ulysses.row_shard(19385, 8, 7) == (2424, 16968, 2417)
+    assert ulysses.row_shard(3, 4, 2) == (1, 2, 1)
+    assert ulysses.row_shard(3, 4, 3) == (1, 3, 0)            # a rank with only padding
+    assert ulysses.row_shard(0, 4, 2) == (0, 0, 0)
