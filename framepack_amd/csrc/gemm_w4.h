@@ -7,7 +7,7 @@
 // only twice per K tile (every 64 MFMAs = 1024 matrix-pipe cycles).
 //
 // Same LDS image, swizzle, operand swap (token row on the lane) and epilogues as gemm_pipeline.h.
-//   * K tile = 64 (128 B per row), two 64 KiB buffers, staged as THREE units per tile: A-h0 / A-h1 (rows 0-63 /
+//   * K tile = 64 (128 B per row), two buffers of 32 KiB per operand, staged as THREE units per tile: A-h0 / A-h1 (rows 0-63 /
 //     64-127 of each wave row) and W (whole).  A K tile is two phases: phase p multiplies A-h{p} (4 row tiles)
 //     with all of W (8 column tiles, fragments kept in registers across both phases) = 64 MFMAs.
 //   * A unit is re-staged right after the barrier that follows its last read: during P0(t) the wave issues
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr int BKE = 128 / (int)sizeof(T);
     constexpr int CE = 16 / (int)sizeof(T);
     constexpr int KS = mfma_op<T>::KS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // [2][A 32 KiB | W 32 KiB] + stage 32 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A[2] 32 KiB each | W[2] | stage 32 KiB
+    constexpr unsigned W_BASE = 2 * OP_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,8 +84,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // ---- DMA sources.  One instruction = 8 tile rows x 128 B.  A half unit = 16 instructions (4 per wave),
     //      W unit = 32 instructions (8 per wave).
     const int prow = lane >> 3, pch = lane & 7;
-    const T* pa[2][4];
-    const T* pw[8];
+    // per-lane byte offsets of the DMA / load rows from the tile's first row (the tile base and the K offset are
+    // wave-uniform and stay in scalar registers: the loads take the address as scalar base + 32-bit lane offset)
+    unsigned pa[2][4], pw[8];
+    const char *abase = nullptr, *wbase = nullptr;
     int arow0[2][4], wrow0[8];
     unsigned cpos[2][4];        // AMODE 1: output position of each DMA row, packed t << 22 | h << 11 | w
     int m0 = 0, n0 = 0;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             for (int j = 0; j < 4; ++j) {
                 const int ar = arow0[h][j] + prow;
                 if (AMODE == 0) {
-                    pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + (pch ^ ((ar >> 1) & 7)) * CE;
+                    pa[h][j] = (unsigned)(min(m0 + ar, M - 1) - m0) * (unsigned)(lda * sizeof(T)) + (pch ^ ((ar >> 1) & 7)) * 16;
                 } else {
                     const int m = min(m0 + ar, M - 1);
                     cpos[h][j] = (unsigned)(m % cg.Wo) | ((unsigned)((m / cg.Wo) % cg.Ho) << 11) |
@@ -128,16 +131,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int wrw = wrow0[j] + prow;
-            pw[j] = W + (int64_t)min(n0 + wrw, N - 1) * ldw + (pch ^ ((wrw >> 1) & 7)) * CE;
+            pw[j] = (unsigned)(min(n0 + wrw, N - 1) - n0) * (unsigned)(ldw * sizeof(T)) + (pch ^ ((wrw >> 1) & 7)) * 16;
         }
+        abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
+        wbase = reinterpret_cast<const char*>(W + (int64_t)n0 * ldw);
     };
     const int nk = K / BKE;
-    auto issue_a1 = [&](int h, int j, int t) __attribute__((always_inline)) {
-        t = min(t, nk - 1);
-        unsigned char* dst = smem + (t & 1) * BUF_BYTES;
+    auto src_a = [&](int h, int j, int t) __attribute__((always_inline)) -> const T* {
         if (AMODE == 0) {
             const int64_t koff = (int64_t)t * BKE + ((t * BKE >= k1) ? a2_delta : 0);
-            dma16(pa[h][j] + koff, dst + arow0[h][j] * 128);
+            asm volatile("" : "+v"(pa[h][j]));      // keeps "base + lane offset" from being hoisted as a 64-bit register pair
+            return reinterpret_cast<const T*>(abase + koff * (int64_t)sizeof(T) + pa[h][j]);
         } else {
             const int k0 = t * BKE;
             const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
@@ -150,13 +154,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             const int ts = cg.st ? ((tu + 1) >> 1) : tu;
             const int hs = hu >> cg.sh, ws = wu >> cg.sw;
             const int64_t off = ((int64_t)(ts * cg.Hi + hs) * cg.Wi + ws) * cg.Cin + c0 + cch;
-            dma16(A + off, dst + arow0[h][j] * 128);
+            return A + off;
         }
+    };
+    auto src_w = [&](int j, int t) __attribute__((always_inline)) -> const T* {
+        asm volatile("" : "+v"(pw[j]));
+        return reinterpret_cast<const T*>(wbase + (int64_t)t * (BKE * (int)sizeof(T)) + pw[j]);
+    };
+    auto issue_a1 = [&](int h, int j, int t) __attribute__((always_inline)) {
+        t = min(t, nk - 1);
+        dma16(src_a(h, j, t), smem + (t & 1) * OP_BYTES + arow0[h][j] * 128);
     };
     auto issue_w1 = [&](int j, int t) __attribute__((always_inline)) {
         t = min(t, nk - 1);
-        dma16(pw[j] + (int64_t)t * BKE, smem + (t & 1) * BUF_BYTES + OP_BYTES + wrow0[j] * 128);
+        dma16(src_w(j, t), smem + W_BASE + (t & 1) * OP_BYTES + wrow0[j] * 128);
     };
+
     // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (28 loads per wave)
     auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -175,16 +188,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     const int fr = lane & 15, fq = lane >> 4;
     constexpr unsigned SECOND = SCALED ? 16u : 64u;
     const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
-    // One address register per (buffer, K step) and operand; every other offset is an immediate below 64 KiB.  The
-    // second buffer's bases are made opaque so that the compiler does not fold them into 30-odd distinct addresses.
-    unsigned a_rd[2][2], w_rd[2][2];
+    // One address register per K step and operand; every other offset - the buffer's included: the two A buffers
+    // are neighbours, and so are the two W buffers - is an instruction immediate below 64 KiB.
+    unsigned a_rd[2], w_rd[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        a_rd[0][ks] = (unsigned)(wr * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
-        w_rd[0][ks] = (unsigned)(wc * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
-        a_rd[1][ks] = a_rd[0][ks] + BUF_BYTES;
-        w_rd[1][ks] = w_rd[0][ks] + BUF_BYTES;
-        asm volatile("" : "+v"(a_rd[1][ks]), "+v"(w_rd[1][ks]));
+        a_rd[ks] = (unsigned)(wr * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
+        w_rd[ks] = W_BASE + (unsigned)(wc * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
+        asm volatile("" : "+v"(a_rd[ks]), "+v"(w_rd[ks]));
     }
 
     // The 64 accumulator tiles live in AGPRs a[0:255] that the compiler never sees: tile (mi, ni) = a[(mi*8+ni)*4 .. +3].
@@ -202,10 +213,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     frag_t wf[2][8], af[4];
 
     auto rd_a = [&](auto BUF, auto P, auto G) __attribute__((always_inline)) {
-        af[G & 3] = *reinterpret_cast<const frag_t*>(smem + a_rd[BUF][G >> 2] + (P * 64 + (G & 3) * 16) * 128);
+        af[G & 3] = *reinterpret_cast<const frag_t*>(smem + a_rd[G >> 2] + BUF * OP_BYTES + (P * 64 + (G & 3) * 16) * 128);
     };
     auto rd_w = [&](auto BUF, auto KS_, auto NI) __attribute__((always_inline)) {
-        wf[KS_][NI] = *reinterpret_cast<const frag_t*>(smem + w_rd[BUF][KS_] + OP_BYTES + (NI * 16) * 128);
+        wf[KS_][NI] = *reinterpret_cast<const frag_t*>(smem + w_rd[KS_] + BUF * OP_BYTES + (NI * 16) * 128);
     };
     // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0)
     auto mfma1 = [&](auto P, auto G, auto NI, auto ZC) __attribute__((always_inline)) {
@@ -216,10 +227,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     //   P0(t) issues A-h1(t+1);  P1(t) issues A-h0(t+2) and W(t+2)  (W's fragments sit in registers after P0).
     auto slot = [&](auto BUF, auto P, int t, auto G, auto K_) __attribute__((always_inline)) {
         constexpr int g = G, k = K_;
+        constexpr int g4 = g < 4 ? g : 0;
         if constexpr (k == 0) rd_a(BUF, P, ic<g + 2>{});
         if constexpr (P == 0) {
-            if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * (g < 4 ? g : 0)>{});
-            if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * (g < 4 ? g : 0) + 1>{});
+            if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * g4>{});
+            if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * g4 + 1>{});
             if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1);
         } else {
             if constexpr (k == 2) {
@@ -265,11 +277,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // Stage image: [16 rows][256 B], 16-B chunk index XORed with the row (conflict-free b128 reads, 2-way b64 writes).
     typedef TO Tx8 __attribute__((ext_vector_type(8)));
     Tx8 rpre[2][4];          // EPI 3/4: residual rows (row layout) of two row tiles, a ring filled 2 tiles ahead
+    // (the epilogue derives its lane terms from an opaque copy of the lane number: otherwise the compiler computes
+    //  some fifty per-lane offsets at kernel entry and holds them in registers across every main loop)
+    auto opaque_lane = [&]() __attribute__((always_inline)) {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
     auto load_resid = [&](int em0, int en0, int mi) __attribute__((always_inline)) {
-        const int gcol = en0 + wc * 128 + (lane & 15) * 8;
+        const int el = opaque_lane();
+        const int gcol = en0 + wc * 128 + (el & 15) * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = em0 + wr * 128 + mi * 16 + (lane >> 4) + 4 * i;
+            const int m = em0 + wr * 128 + mi * 16 + (el >> 4) + 4 * i;
             rpre[mi & 1][i] = Tx8{};
             if (gcol < N && m < M) rpre[mi & 1][i] = *reinterpret_cast<const Tx8*>(R + (int64_t)m * ldr + gcol);
         }
@@ -280,6 +300,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         unsigned char* stage = smem + stage_off;
         Tx4 bv[8], gv[8];
         f32x4 ws[8];
+        const int el = opaque_lane();
+        const int fr = el & 15, fq = el >> 4;                  // shadow the main loop's
         const int nb = en0 + wc * 128 + 4 * fq;
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) {
@@ -289,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if (EPI == 3) gv[ni] = *reinterpret_cast<const Tx4*>(gate + n);
             if (SCALED) ws[ni] = *reinterpret_cast<const f32x4*>(w_scale + n);
         }
-        const int lrow = lane >> 4, lchk = lane & 15;
+        const int lrow = el >> 4, lchk = el & 15;
         const int gcol = en0 + wc * 128 + lchk * 8;            // first of this lane's 8 columns in row layout
         const bool col_ok = gcol < N;                          // N % 8 == 0: a chunk is inside or outside
         static_for<8>([&](auto MI_) __attribute__((always_inline)) {

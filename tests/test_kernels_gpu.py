@@ -107,10 +107,19 @@ def test_rel_l1():
 
 
 # ------------------------------------------------------------------ K5
+@pytest.fixture(params=[0, 1], ids=["eight_wave", "four_wave"])
+def gemm_variant(request):
+    """Both main loop generations the library holds (fp_debug_gemm_variant), the default restored afterwards."""
+    from framepack_amd import lib as fplib
+    old = fplib.load().fp_debug_gemm_variant(request.param)
+    yield request.param
+    fplib.load().fp_debug_gemm_variant(old)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (1, 8, 64), (300, 768, 256), (1408, 1792, 256), (777, 3072, 3072),
                                    (513, 264, 1280)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
-def test_gemm_epilogues(M, N, K, epi):
+def test_gemm_epilogues(M, N, K, epi, gemm_variant):
     a, w, b = randn(M, K, seed=1), randn(N, K, seed=2, scale=1 / math.sqrt(K)), randn(N, seed=3)
     lin = a.float() @ w.float().T + b.float()
     gelu = torch.nn.functional.gelu(lin, approximate="tanh")
@@ -131,7 +140,7 @@ def test_gemm_epilogues(M, N, K, epi):
     assert got.shape == (M, N) and rel_l2(got, ref) < 4e-3
 
 
-def test_gemm_strided_two_segment_and_inplace_residual():
+def test_gemm_strided_two_segment_and_inplace_residual(gemm_variant):
     M, N, K1, K2 = 389, 512, 256, 1024
     buf = randn(M, 3 * 256 + K2 + 128, seed=1)                  # [k | v | o | mlp | pad]
     w, b = randn(N, K1 + K2, seed=2, scale=0.03), randn(N, seed=3)

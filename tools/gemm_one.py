@@ -21,7 +21,11 @@ if epi >= 3:
     kw = dict(resid=torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16))
     if epi == 3:
         kw["gate"] = b
+variants = [int(v) for v in os.environ.get("FP_GEMM_VARIANTS", "1").split(",")]
+from framepack_amd import lib as fplib  # noqa: E402
 for _ in range(iters):
-    ops.gemm(a, w, b, out=out, epilogue=epi, **kw)
+    for v in variants:
+        fplib.load().fp_debug_gemm_variant(v)
+        ops.gemm(a, w, b, out=out, epilogue=epi, **kw)
     torch.nn.functional.linear(a, w, b)
 torch.cuda.synchronize()
