@@ -439,6 +439,8 @@ int launch_w4(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* 
               void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
               const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
               const float* w_scale = nullptr) {
+    // lane offsets inside a tile are 32-bit: 255 rows x the row stride in bytes has to fit
+    if (lda >= (int64_t(1) << 22) || ldw >= (int64_t(1) << 22)) return (int)hipErrorInvalidValue;
     const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
     constexpr int smem = 2 * BUF_BYTES + 4 * 8192;        // operand buffers + the epilogue's row stage
     auto kern = gemm_w4_kernel<T, TO, EPI, AMODE>;
