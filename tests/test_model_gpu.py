@@ -133,17 +133,20 @@ def test_teacache_schedule_matches_oracle(tiny):
 def test_fp8_weights_follow_reference_w8a16_semantics(tiny):
     """ref utils/fp8_optimization_utils.py: E4M3 weights + per-tensor scale, dequantise then bf16 GEMM."""
     from oracle import fp8_oracle as F8
+    from framepack_amd import weights
     m, _ = tiny
     cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
     sd = {k: v.cpu() for k, v in m.state_dict().items()}
     q = F8.quantize_state_dict(sd)
+    # the product's load sequence (ref framepack/models.py:255-275): optimise, patch, assign-load
+    q_prod = weights.optimize_state_dict_with_fp8({k: v.clone() for k, v in sd.items()}, None,
+                                                  ["transformer_blocks", "single_transformer_blocks"], ["norm"])
+    assert set(q_prod) == set(q)
+    assert all(torch.equal(q_prod[k].view(torch.uint8) if v.dtype == torch.float8_e4m3fn else q_prod[k],
+                           v.view(torch.uint8) if v.dtype == torch.float8_e4m3fn else v) for k, v in q.items())
     m8 = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_TINY).to(BF)
-    # what ref apply_fp8_monkey_patch does: a scale_weight buffer on every quantised nn.Linear, then assign-load
-    for name, mod in m8.named_modules():
-        if name + ".scale_weight" in q:
-            assert isinstance(mod, torch.nn.Linear)
-            mod.register_buffer("scale_weight", torch.tensor(1.0, dtype=BF))
-    m8.load_state_dict(q, strict=True, assign=True)
+    weights.apply_fp8_monkey_patch(m8, q_prod)
+    m8.load_state_dict(q_prod, strict=True, assign=True)
     m8 = m8.to(DEV).eval()
     kw = synthetic.make_inputs(dtype=BF, **CASES["config1"])
     P32 = {k: v.float() for k, v in q.items() if v.dtype != torch.float8_e4m3fn}
