@@ -40,8 +40,11 @@ constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
 // tap = (dt * 3 + dh) * 3 + dw.  Padding is REPLICATE (indices clamp), causal in time (two frames in front,
 // none behind); the source may be a nearest-neighbour upsampling of a smaller [Ti, Hi, Wi] volume that is
 // never materialised (st/sh/sw = log2 of the factor; in time the first frame is not doubled).
+// st/sh/sw = 1: the input is nearest-upsampled x2 on that axis on the fly (decoder); dt/dh/dw = 1: the convolution
+// has stride 2 on that axis (encoder downsamplers).  hmax/wmax: upper clamp of the tap coordinate (replicate
+// padding) in the coordinate system the taps are applied in (upsampled input, or input).
 struct ConvGeom {
-    int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw;
+    int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw, dt, dh, dw, hmax, wmax;
 };
 
 // OCP e4m3 storage type of the fp8 path (K6): one byte per element, so a 128-B LDS row holds 128 K values.
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
                 pa[h][j] = A + (int64_t)min(m0 + ar, M - 1) * lda + (pch ^ ((ar >> 1) & 7)) * CE;
             } else {
                 const int m = min(m0 + ar, M - 1);
-                cw[h][j] = m % cg.Wo;
-                ch[h][j] = (m / cg.Wo) % cg.Ho;
-                ct[h][j] = m / (cg.Wo * cg.Ho);
+                cw[h][j] = (m % cg.Wo) << cg.dw;            // centre tap in tap coordinates
+                ch[h][j] = ((m / cg.Wo) % cg.Ho) << cg.dh;
+                ct[h][j] = (m / (cg.Wo * cg.Ho)) << cg.dt;
                 cch[h][j] = (pch ^ ((ar >> 1) & 7)) * CE;
             }
             pw[h][j] = W + (int64_t)min(n0 + wrw, N - 1) * ldw + (pch ^ ((wrw >> 1) & 7)) * CE;
@@ -171,8 +174,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int tu = max(ct[h][j] + dt, 0);
-                const int hu = min(max(ch[h][j] + dh, 0), cg.Ho - 1);
-                const int wu = min(max(cw[h][j] + dw, 0), cg.Wo - 1);
+                const int hu = min(max(ch[h][j] + dh, 0), cg.hmax);
+                const int wu = min(max(cw[h][j] + dw, 0), cg.wmax);
                 const int ts = cg.st ? ((tu + 1) >> 1) : tu;
                 const int hs = hu >> cg.sh, ws = wu >> cg.sw;
                 const int64_t off = ((int64_t)(ts * cg.Hi + hs) * cg.Wi + ws) * cg.Cin + c0 + cch[h][j];

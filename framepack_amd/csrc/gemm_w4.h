@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     unsigned pa[2][4], pw[8];
     const char *abase = nullptr, *wbase = nullptr;
     int arow0[2][4], wrow0[8];
-    unsigned cpos[2][4];        // AMODE 1: output position of each DMA row, packed t << 22 | h << 11 | w
+    unsigned cpos[2][4];        // AMODE 1: centre tap of each DMA row in tap coordinates, packed t << 22 | h << 11 | w
     int m0 = 0, n0 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     pa[h][j] = (unsigned)(min(m0 + ar, M - 1) - m0) * (unsigned)(lda * sizeof(T)) + (pch ^ ((ar >> 1) & 7)) * 16;
                 } else {
                     const int m = min(m0 + ar, M - 1);
-                    cpos[h][j] = (unsigned)(m % cg.Wo) | ((unsigned)((m / cg.Wo) % cg.Ho) << 11) |
-                                 ((unsigned)(m / (cg.Wo * cg.Ho)) << 22);
+                    cpos[h][j] = (unsigned)((m % cg.Wo) << cg.dw) | ((unsigned)(((m / cg.Wo) % cg.Ho) << cg.dh) << 11) |
+                                 ((unsigned)((m / (cg.Wo * cg.Ho)) << cg.dt) << 22);
                 }
             }
 #pragma unroll
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
             const int dt = tap / 9 - 2, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
             const int tu = max((int)(cpos[h][j] >> 22) + dt, 0);
-            const int hu = min(max((int)((cpos[h][j] >> 11) & 2047) + dh, 0), cg.Ho - 1);
-            const int wu = min(max((int)(cpos[h][j] & 2047) + dw, 0), cg.Wo - 1);
+            const int hu = min(max((int)((cpos[h][j] >> 11) & 2047) + dh, 0), cg.hmax);
+            const int wu = min(max((int)(cpos[h][j] & 2047) + dw, 0), cg.wmax);
             // source chunk of this lane: the row's swizzle term is (prow >> 1) | 4 (j & 1)  (rows come 8 per instruction)
             const int cch = (pch ^ (prow >> 1) ^ ((j & 1) << 2)) * CE;
             const int ts = cg.st ? ((tu + 1) >> 1) : tu;

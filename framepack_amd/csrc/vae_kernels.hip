@@ -38,6 +38,23 @@ extern "C" int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, c
     }
 }
 
+static int conv_launch(const void* x, const void* w, const void* bias, void* y, const fp_gemm::ConvGeom& cg, int Cout,
+                       const void* resid, hipStream_t st) {
+    using namespace fp_gemm;
+    const int64_t M64 = (int64_t)cg.To * cg.Ho * cg.Wo;
+    FP_REQUIRE(M64 < (1ll << 31) && (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin < (1ll << 40));
+    // centre taps are packed t << 22 | h << 11 | w in gemm_w4.h, in tap coordinates (strided: twice the output's)
+    FP_REQUIRE((cg.To << cg.dt) < 1024 && (cg.Ho << cg.dh) < 2048 && (cg.Wo << cg.dw) < 2048);
+    const int M = (int)M64, N = Cout, K = 27 * cg.Cin;
+    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
+    const bool wide = ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
+    if (resid)
+        return wide ? launch_w4<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st)
+                    : launch<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st);
+    return wide ? launch_w4<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st)
+                : launch<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
+}
+
 // y[To,Ho,Wo,Cout] = conv3x3x3_causal_replicate(upsample(x[Ti,Hi,Wi,Cin])) + bias (+ resid)
 // w: [Cout][27][Cin] (tap-major, channel-minor);  up_t/up_h/up_w in {1, 2};  To = up_t == 2 ? 2 Ti - 1 : Ti.
 extern "C" int fp_conv3d_causal_f16(const void* x, const void* w, const void* bias, void* y, int Ti, int Hi, int Wi,
@@ -49,22 +66,30 @@ extern "C" int fp_conv3d_causal_f16(const void* x, const void* w, const void* bi
     FP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 7) == 0);
     FP_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0);
     FP_REQUIRE(!resid || ((uintptr_t)resid & 7) == 0);
-    ConvGeom cg;
+    ConvGeom cg{};
     cg.Ti = Ti; cg.Hi = Hi; cg.Wi = Wi;
     cg.To = up_t == 2 ? 2 * Ti - 1 : Ti; cg.Ho = Hi * up_h; cg.Wo = Wi * up_w;
     cg.Cin = Cin; cg.st = up_t - 1; cg.sh = up_h - 1; cg.sw = up_w - 1;
-    const int64_t M64 = (int64_t)cg.To * cg.Ho * cg.Wo;
-    FP_REQUIRE(M64 < (1ll << 31) && (int64_t)Ti * Hi * Wi * Cin < (1ll << 40));
-    FP_REQUIRE(cg.To < 1024 && cg.Ho < 2048 && cg.Wo < 2048);          // packed positions in gemm_w4.h
-    const int M = (int)M64, N = Cout, K = 27 * Cin;
-    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
-    hipStream_t st = (hipStream_t)stream;
-    const bool wide = ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
-    if (resid)
-        return wide ? launch_w4<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st)
-                    : launch<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st);
-    return wide ? launch_w4<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st)
-                : launch<f16, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
+    cg.hmax = cg.Ho - 1; cg.wmax = cg.Wo - 1;
+    return conv_launch(x, w, bias, y, cg, Cout, resid, (hipStream_t)stream);
+}
+
+// Strided form (the encoder's downsamplers): y[To,Ho,Wo,Cout] = conv3x3x3 with stride (dn_t, dn_h, dn_w), each 1 or 2,
+// over x padded causally in time (two frames in front) and by one voxel on every spatial side, replicate mode:
+// To = (Ti - 1) / dn_t + 1, Ho = (Hi - 1) / dn_h + 1, Wo = (Wi - 1) / dn_w + 1.
+extern "C" int fp_conv3d_causal_strided_f16(const void* x, const void* w, const void* bias, void* y, int Ti, int Hi,
+                                            int Wi, int dn_t, int dn_h, int dn_w, int Cin, int Cout, void* stream) {
+    using namespace fp_gemm;
+    FP_REQUIRE(x && w && y && Ti > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cin % BK == 0 && Cout > 0 && Cout % 8 == 0);
+    FP_REQUIRE((dn_t == 1 || dn_t == 2) && (dn_h == 1 || dn_h == 2) && (dn_w == 1 || dn_w == 2));
+    FP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 7) == 0);
+    FP_REQUIRE(!bias || ((uintptr_t)bias & 7) == 0);
+    ConvGeom cg{};
+    cg.Ti = Ti; cg.Hi = Hi; cg.Wi = Wi;
+    cg.To = (Ti - 1) / dn_t + 1; cg.Ho = (Hi - 1) / dn_h + 1; cg.Wo = (Wi - 1) / dn_w + 1;
+    cg.Cin = Cin; cg.dt = dn_t - 1; cg.dh = dn_h - 1; cg.dw = dn_w - 1;
+    cg.hmax = Hi - 1; cg.wmax = Wi - 1;
+    return conv_launch(x, w, bias, y, cg, Cout, nullptr, (hipStream_t)stream);
 }
 
 namespace {

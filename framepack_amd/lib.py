@@ -31,6 +31,7 @@ SIGNATURES = {
     "fp_quantize_rows_fp8": [P, L, I, P, L, I, P, L, P, I, P],
     "fp_gemm_fp8_bf16": [P, L, P, P, L, P, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_conv3d_causal_f16": [P, P, P, P, I, I, I, I, I, I, I, I, P, P],
+    "fp_conv3d_causal_strided_f16": [P, P, P, P, I, I, I, I, I, I, I, I, P],
     "fp_groupnorm_workspace_floats": [I],
     "fp_groupnorm_stats_f16": [P, L, I, I, F, P, P, P],
     "fp_groupnorm_apply_f16": [P, P, L, I, I, P, P, P, I, P],

@@ -324,6 +324,25 @@ def conv3d_causal(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
+def conv3d_causal_strided(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                          stride: Tuple[int, int, int]) -> torch.Tensor:
+    """The same convolution with stride 1 or 2 per axis (the encoder's downsamplers): output voxel o reads input
+    voxels s*o-2..s*o in time and s*o-1..s*o+1 in space, clamped into the volume."""
+    _dev(x, weight, bias)
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == F16 and weight.dtype == F16 and weight.is_contiguous()
+    Ti, Hi, Wi, Cin = x.shape
+    Cout = weight.shape[0]
+    assert weight.shape[1] == 27 * Cin
+    out = torch.empty(((Ti - 1) // stride[0] + 1, (Hi - 1) // stride[1] + 1, (Wi - 1) // stride[2] + 1, Cout),
+                      dtype=F16, device=x.device)
+    if bias is not None:
+        assert bias.dtype == F16 and bias.numel() == Cout and bias.is_contiguous()
+    _lib.check(_lib.load().fp_conv3d_causal_strided_f16(x.data_ptr(), weight.data_ptr(), _ptr(bias), out.data_ptr(), Ti, Hi,
+                                                        Wi, stride[0], stride[1], stride[2], Cin, Cout, _stream(x)),
+               "fp_conv3d_causal_strided_f16")
+    return out
+
+
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-6,
               silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """GroupNorm (+SiLU) over a channels-last volume x [..., C] fp16 (all leading dims are the group's extent)."""

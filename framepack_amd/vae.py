@@ -1,4 +1,4 @@
-"""Host mirror of the VAE decode boundary: `AutoencoderKLHunyuanVideo.decode` + `vae_decode`.
+"""Host mirror of the VAE boundary: `AutoencoderKLHunyuanVideo.decode` + `vae_decode`, `.encode` + `vae_encode`.
 
 The reference's code for this path is ref: diffusers_helper/hunyuan.py:93-103 (`vae_decode`) and :61-89
 (`vae_decode_fake`); the model class itself is diffusers 0.33.1's `AutoencoderKLHunyuanVideo`
@@ -11,9 +11,12 @@ GroupNorm+SiLU is one fused pass after a deterministic statistics pass, the resn
 convolution's epilogue, and the mid-block attention (one head of 512 channels, frame-causal) runs as
 GEMM -> masked softmax -> GEMM on materialised scores (288 GB of HBM make that the simple choice).
 
+The encode half (ref: diffusers_helper/hunyuan.py:107-110 `vae_encode`, run on single images: worker.py:246-272)
+uses the same kernels: the downsamplers are the same implicit GEMM with a stride of 2 in its gather
+(`fp_conv3d_causal_strided_f16`); parameter names `encoder.*` / `quant_conv.*` as in a diffusers checkpoint.
+
 PARITY UNPINNED: the diffusers source is not available offline; the algorithm is the one restated in
-oracle/vae_oracle.py (see its header).  The encoder half (`vae_encode`, run once per job) is not built.
-There is no CPU path: `decode` raises for CPU tensors.
+oracle/vae_oracle.py (see its header).  There is no CPU path: `decode` / `encode` raise for CPU tensors.
 """
 from __future__ import annotations
 
@@ -77,6 +80,32 @@ class _UpBlock(nn.Module):
             self.upsamplers = nn.ModuleList([_Upsample(cout)])
 
 
+class _Downsample(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.conv = _CausalConv3d(c, c, 3)
+
+
+class _DownBlock(nn.Module):
+    def __init__(self, cin: int, cout: int, layers: int, groups: int, stride: Optional[Tuple[int, int, int]]):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if j == 0 else cout, cout, groups) for j in range(layers)])
+        self.stride = stride
+        if stride is not None:
+            self.downsamplers = nn.ModuleList([_Downsample(cout)])
+
+
+class _Encoder(nn.Module):
+    def __init__(self, in_ch: int, latent: int, chans: Tuple[int, ...], layers: int, groups: int, add_attention: bool,
+                 plan: List[Tuple[int, int, Optional[Tuple[int, int, int]]]]):
+        super().__init__()
+        self.conv_in = _CausalConv3d(in_ch, chans[0], 3)
+        self.down_blocks = nn.ModuleList([_DownBlock(ci, co, layers, groups, s) for ci, co, s in plan])
+        self.mid_block = _MidBlock(chans[-1], groups, add_attention)
+        self.conv_norm_out = nn.GroupNorm(groups, chans[-1], eps=1e-6)
+        self.conv_out = _CausalConv3d(chans[-1], 2 * latent, 3)
+
+
 class _Decoder(nn.Module):
     def __init__(self, latent: int, out_ch: int, chans: Tuple[int, ...], layers: int, groups: int, add_attention: bool,
                  plan: List[Tuple[int, int, Optional[Tuple[int, int, int]]]]):
@@ -103,6 +132,20 @@ def _up_block_plan(chans: Tuple[int, ...], spatial_ratio: int, temporal_ratio: i
     return plan
 
 
+def _down_block_plan(chans: Tuple[int, ...], spatial_ratio: int, temporal_ratio: int):
+    """Which down block strides what (diffusers HunyuanVideoEncoder3D.__init__): with ratios 8/4 and four blocks,
+    block 0 halves H,W, blocks 1 and 2 halve T,H,W, block 3 nothing."""
+    import math
+    n, n_sp, n_t = len(chans), int(math.log2(spatial_ratio)), int(math.log2(temporal_ratio))
+    plan, out_ch = [], chans[0]
+    for i in range(n):
+        prev, out_ch = out_ch, chans[i]
+        sp = i < n_sp
+        tm = (i >= n - 1 - n_t) and i != n - 1
+        plan.append((prev, out_ch, ((2 if tm else 1), (2 if sp else 1), (2 if sp else 1)) if (sp or tm) else None))
+    return plan
+
+
 def _pad_to(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
@@ -111,8 +154,31 @@ class DecoderOutput(SimpleNamespace):
     pass
 
 
+class DiagonalGaussianDistribution:
+    """What `vae.encode(x).latent_dist` offers in diffusers: parameters [B, 2C, ...] = (mean | logvar), the log
+    variance clamped to [-30, 20]; `sample(generator)` = mean + std * N(0, 1), `mode()` = mean."""
+
+    def __init__(self, parameters: torch.Tensor):
+        self.parameters = parameters
+        self.mean, logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        noise = torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+
+class AutoencoderKLOutput(SimpleNamespace):
+    pass
+
+
 class AutoencoderKLHunyuanVideo(nn.Module):
-    """Decode half of diffusers' AutoencoderKLHunyuanVideo on MI355X kernels (see module docstring)."""
+    """diffusers' AutoencoderKLHunyuanVideo on MI355X kernels (see module docstring)."""
 
     def __init__(self, in_channels: int = 3, out_channels: int = 3, latent_channels: int = 16,
                  block_out_channels: Tuple[int, ...] = (128, 256, 512, 512), layers_per_block: int = 2,
@@ -128,7 +194,13 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         plan = _up_block_plan(tuple(block_out_channels), spatial_compression_ratio, temporal_compression_ratio)
         self.decoder = _Decoder(latent_channels, out_channels, tuple(block_out_channels), layers_per_block,
                                 norm_num_groups, mid_block_add_attention, plan)
+        self.encoder = _Encoder(in_channels, latent_channels, tuple(block_out_channels), layers_per_block,
+                                norm_num_groups, mid_block_add_attention,
+                                _down_block_plan(tuple(block_out_channels), spatial_compression_ratio,
+                                                 temporal_compression_ratio))
+        self.quant_conv = nn.Conv3d(2 * latent_channels, 2 * latent_channels, 1)
         self.post_quant_conv = nn.Conv3d(latent_channels, latent_channels, 1)
+        self._encoder_loaded = True        # random-init counts as loaded; a decoder-only checkpoint clears it
         # diffusers defaults: framewise (temporally tiled) decoding on, spatial tiling / slicing off
         self.use_framewise_decoding = True
         self.tile_sample_min_num_frames = 16
@@ -152,11 +224,16 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         pass
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
-        """A full diffusers checkpoint also holds `encoder.*` / `quant_conv.*`; the encode half is not built, so
-        those keys are dropped before the strict check of the decode half."""
-        sd = {k: v for k, v in state_dict.items() if not (k.startswith("encoder.") or k.startswith("quant_conv."))}
+        """A full diffusers checkpoint holds both halves.  A decoder-only state dict (no `encoder.*` / `quant_conv.*`
+        key at all) loads strictly into the decode half and leaves `encode` unavailable."""
         self._prep = None
-        return super().load_state_dict(sd, strict=strict, assign=assign)
+        enc_keys = [k for k in state_dict if k.startswith("encoder.") or k.startswith("quant_conv.")]
+        if enc_keys or not strict:
+            self._encoder_loaded = bool(enc_keys)
+            return super().load_state_dict(state_dict, strict=strict, assign=assign)
+        self._encoder_loaded = False
+        mine = {k: v for k, v in self.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+        return super().load_state_dict({**mine, **state_dict}, strict=True, assign=assign)
 
     def _apply(self, fn, *a, **kw):
         self._prep = None
@@ -170,10 +247,10 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         dev = self.device
         W: Dict[str, torch.Tensor] = {}
 
-        def conv3(name: str, m: _CausalConv3d) -> None:
+        def conv3(name: str, m: _CausalConv3d, cout_multiple: int = 8) -> None:
             w = m.conv.weight.detach().to(dev, F16)                           # [Cout, Cin, 3, 3, 3]
             cout, cin = w.shape[:2]
-            cinp, coutp = _pad_to(cin, 64), _pad_to(cout, 8)
+            cinp, coutp = _pad_to(cin, 64), _pad_to(cout, cout_multiple)
             wp = torch.zeros(coutp, 27, cinp, dtype=F16, device=dev)
             wp[:cout, :, :cin] = w.permute(0, 2, 3, 4, 1).reshape(cout, 27, cin)
             bp = torch.zeros(coutp, dtype=F16, device=dev)
@@ -203,20 +280,43 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         bpq = torch.zeros(latp, dtype=F16, device=dev)
         bpq[:lat] = self.post_quant_conv.bias.detach().to(dev, F16)
         W["pq.w"], W["pq.b"] = wpq, bpq
-        conv3("conv_in", d.conv_in)
-        resnet("mid.0", d.mid_block.resnets[0])
-        resnet("mid.1", d.mid_block.resnets[1])
-        att = d.mid_block.attentions[0]
-        if att is not None:
+        def attention(name: str, att: Optional[_Attention]) -> None:
+            if att is None:
+                return
             c = att.to_q.weight.shape[0]
-            norm("attn.gn", att.group_norm)
+            norm(name + ".gn", att.group_norm)
             scale = c ** -0.5                      # one head of c channels; folded into the q projection
             wq = (att.to_q.weight.detach().float() * scale).to(dev, F16)
             bq = (att.to_q.bias.detach().float() * scale).to(dev, F16)
-            W["attn.qkv.w"] = torch.cat([wq, att.to_k.weight.detach().to(dev, F16), att.to_v.weight.detach().to(dev, F16)]).contiguous()
-            W["attn.qkv.b"] = torch.cat([bq, att.to_k.bias.detach().to(dev, F16), att.to_v.bias.detach().to(dev, F16)]).contiguous()
-            W["attn.o.w"] = att.to_out[0].weight.detach().to(dev, F16).contiguous()
-            W["attn.o.b"] = att.to_out[0].bias.detach().to(dev, F16).contiguous()
+            W[name + ".qkv.w"] = torch.cat([wq, att.to_k.weight.detach().to(dev, F16), att.to_v.weight.detach().to(dev, F16)]).contiguous()
+            W[name + ".qkv.b"] = torch.cat([bq, att.to_k.bias.detach().to(dev, F16), att.to_v.bias.detach().to(dev, F16)]).contiguous()
+            W[name + ".o.w"] = att.to_out[0].weight.detach().to(dev, F16).contiguous()
+            W[name + ".o.b"] = att.to_out[0].bias.detach().to(dev, F16).contiguous()
+
+        conv3("conv_in", d.conv_in)
+        resnet("mid.0", d.mid_block.resnets[0])
+        resnet("mid.1", d.mid_block.resnets[1])
+        attention("attn", d.mid_block.attentions[0])
+        if self._encoder_loaded:
+            e = self.encoder
+            conv3("enc.conv_in", e.conv_in)
+            for i, db in enumerate(e.down_blocks):
+                for j, r in enumerate(db.resnets):
+                    resnet(f"enc.down.{i}.{j}", r)
+                if db.stride is not None:
+                    conv3(f"enc.down.{i}.ds", db.downsamplers[0].conv)
+            resnet("enc.mid.0", e.mid_block.resnets[0])
+            resnet("enc.mid.1", e.mid_block.resnets[1])
+            attention("enc.attn", e.mid_block.attentions[0])
+            norm("enc.norm_out", e.conv_norm_out)
+            conv3("enc.conv_out", e.conv_out, cout_multiple=64)           # zero channels up to quant_conv's K tile
+            m2 = 2 * lat
+            m2p = _pad_to(m2, 64)
+            wq = torch.zeros(_pad_to(m2, 8), m2p, dtype=F16, device=dev)
+            wq[:m2, :m2] = self.quant_conv.weight.detach().to(dev, F16).reshape(m2, m2)
+            bq = torch.zeros(_pad_to(m2, 8), dtype=F16, device=dev)
+            bq[:m2] = self.quant_conv.bias.detach().to(dev, F16)
+            W["q.w"], W["q.b"] = wq, bq
         for i, ub in enumerate(d.up_blocks):
             for j, r in enumerate(ub.resnets):
                 resnet(f"up.{i}.{j}", r)
@@ -241,21 +341,21 @@ class AutoencoderKLHunyuanVideo(nn.Module):
             res = h
         return ops.conv3d_causal(c1, W[name + ".conv2.w"], W[name + ".conv2.b"], resid=res)
 
-    def _attention(self, W, h: torch.Tensor) -> torch.Tensor:
+    def _attention(self, W, h: torch.Tensor, name: str = "attn") -> torch.Tensor:
         T, H, Wd, C = h.shape
         S = T * H * Wd
         Sp = _pad_to(S, 64)
         x = h.reshape(S, C)
-        hn = ops.groupnorm(h, W["attn.gn.g"], W["attn.gn.b"], self.config.norm_num_groups, silu=False).reshape(S, C)
+        hn = ops.groupnorm(h, W[name + ".gn.g"], W[name + ".gn.b"], self.config.norm_num_groups, silu=False).reshape(S, C)
         qkv = torch.zeros(Sp, 3 * C, dtype=F16, device=h.device)              # rows >= S stay zero
-        ops.gemm(hn, W["attn.qkv.w"], W["attn.qkv.b"], out=qkv[:S])
+        ops.gemm(hn, W[name + ".qkv.w"], W[name + ".qkv.b"], out=qkv[:S])
         scores = torch.empty(S, Sp, dtype=F16, device=h.device)
         ops.gemm(qkv[:S, :C], qkv[:, C:2 * C], None, out=scores)              # q (pre-scaled) . k^T
         ops.softmax_framecausal_(scores, H * Wd, 1.0)
         vt = qkv[:, 2 * C:].t().contiguous()                                   # [C, Sp]; padding columns are zero
         o = ops.gemm(scores, vt, None)
         del scores
-        out = ops.gemm(o, W["attn.o.w"], W["attn.o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
+        out = ops.gemm(o, W[name + ".o.w"], W[name + ".o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
         return out.reshape(T, H, Wd, C)
 
     def _decode_tile(self, z: torch.Tensor) -> torch.Tensor:
@@ -280,6 +380,50 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         ops.groupnorm(h, W["norm_out.g"], W["norm_out.b"], cfg.norm_num_groups, out=h)
         y = ops.conv3d_causal(h, W["conv_out.w"], W["conv_out.b"])            # [To, Ho, Wo, 8]; channels >= 3 are padding
         return y[..., :cfg.out_channels].permute(3, 0, 1, 2).unsqueeze(0)
+
+    def _encode_tile(self, x: torch.Tensor) -> torch.Tensor:
+        """x: [1, 3, T, H, W] on the GPU -> moments [1, 2*latent, To, H/8, W/8] fp16 (mean | logvar)."""
+        W = self._prepare()
+        cfg = self.config
+        _, cin, T, H, Wd = x.shape
+        v = torch.zeros(T, H, Wd, _pad_to(cin, 64), dtype=F16, device=x.device)
+        v[..., :cin] = x[0].permute(1, 2, 3, 0).to(F16)
+        h = ops.conv3d_causal(v, W["enc.conv_in.w"], W["enc.conv_in.b"])
+        del v
+        for i, db in enumerate(self.encoder.down_blocks):
+            for j in range(len(db.resnets)):
+                h = self._resnet(W, f"enc.down.{i}.{j}", h)
+            if db.stride is not None:
+                h = ops.conv3d_causal_strided(h, W[f"enc.down.{i}.ds.w"], W[f"enc.down.{i}.ds.b"], db.stride)
+        h = self._resnet(W, "enc.mid.0", h)
+        if cfg.mid_block_add_attention:
+            h = self._attention(W, h, "enc.attn")
+        h = self._resnet(W, "enc.mid.1", h)
+        ops.groupnorm(h, W["enc.norm_out.g"], W["enc.norm_out.b"], cfg.norm_num_groups, out=h)
+        y = ops.conv3d_causal(h, W["enc.conv_out.w"], W["enc.conv_out.b"])     # [To, Ho, Wo, 64]; channels >= 32 are zero
+        m = ops.gemm(y.reshape(-1, y.shape[-1]), W["q.w"], W["q.b"]).reshape(*y.shape[:3], -1)
+        return m[..., :2 * cfg.latent_channels].permute(3, 0, 1, 2).unsqueeze(0)
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        """`vae.encode(image).latent_dist`.  Inputs of at most `tile_sample_min_num_frames` frames (the reference
+        encodes single images); diffusers' framewise encoding of longer clips is not built."""
+        if not x.is_cuda:
+            raise RuntimeError("framepack_amd VAE encode runs on the GPU only; there is no CPU fallback")
+        if not self._encoder_loaded:
+            raise RuntimeError("this VAE was loaded from a decoder-only state dict: no encoder weights")
+        if x.dim() != 5 or x.shape[0] != 1 or x.shape[1] != self.config.in_channels:
+            raise ValueError(f"expected an image volume [1, {self.config.in_channels}, T, H, W], got {tuple(x.shape)}")
+        if x.shape[2] > self.tile_sample_min_num_frames:
+            raise ValueError(f"{x.shape[2]} frames: framewise encoding of clips longer than "
+                             f"{self.tile_sample_min_num_frames} frames is not built")
+        sr = self.config.spatial_compression_ratio
+        if x.shape[3] % sr or x.shape[4] % sr:
+            raise ValueError(f"height and width must be multiples of {sr}, got {tuple(x.shape[3:])}")
+        moments = self._encode_tile(x)
+        moments = moments.to(self.dtype) if moments.dtype != self.dtype else moments
+        dist = DiagonalGaussianDistribution(moments)
+        return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 
     @staticmethod
     def _blend_t(a: torch.Tensor, b: torch.Tensor, extent: int) -> torch.Tensor:
@@ -366,6 +510,13 @@ def vae_decode(latents: torch.Tensor, vae: AutoencoderKLHunyuanVideo, image_mode
         return vae.decode(latents.to(device=vae.device, dtype=vae.dtype)).sample
     frames = latents.to(device=vae.device, dtype=vae.dtype).unbind(2)
     return torch.cat([vae.decode(l.unsqueeze(2)).sample for l in frames], dim=2)
+
+
+@torch.no_grad()
+def vae_encode(image: torch.Tensor, vae: AutoencoderKLHunyuanVideo) -> torch.Tensor:
+    """ref: diffusers_helper/hunyuan.py:107-110 (same name and arguments)."""
+    latents = vae.encode(image.to(device=vae.device, dtype=vae.dtype)).latent_dist.sample()
+    return latents * vae.config.scaling_factor
 
 
 # latent -> RGB preview factors, ref: diffusers_helper/hunyuan.py:62-81 (data of the reference, "From comfyui")

@@ -125,6 +125,14 @@ int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, const void* 
 int fp_conv3d_causal_f16(const void* x, const void* w, const void* bias, void* y, int Ti, int Hi, int Wi,
                          int up_t, int up_h, int up_w, int Cin, int Cout, const void* resid, void* stream);
 
+/* The same convolution with stride (dn_t, dn_h, dn_w), each 1 or 2: the encoder's HunyuanVideoDownsampleCausal3D
+ * (diffusers AutoencoderKLHunyuanVideo.encode behind ref diffusers_helper/hunyuan.py:107-110 `vae_encode`).
+ *   y: [To, Ho, Wo, Cout] with To = (Ti-1)/dn_t + 1, Ho = (Hi-1)/dn_h + 1, Wo = (Wi-1)/dn_w + 1; output voxel o reads
+ *   input voxels dn*o - 2 .. dn*o in time and dn*o - 1 .. dn*o + 1 in space, clamped into the volume (= the causal
+ *   replicate padding followed by an unpadded strided convolution). */
+int fp_conv3d_causal_strided_f16(const void* x, const void* w, const void* bias, void* y, int Ti, int Hi, int Wi,
+                                 int dn_t, int dn_h, int dn_w, int Cin, int Cout, void* stream);
+
 /* GroupNorm over a channels-last volume x [rows, C] (rows = T*H*W): stats[g] = (mean, rstd) in fp32, computed
  * in two deterministic stages.  workspace: fp_groupnorm_workspace_floats(C) floats, overwritten. */
 int fp_groupnorm_workspace_floats(int C);

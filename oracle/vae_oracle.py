@@ -1,4 +1,4 @@
-"""Functional CPU restatement of the causal-3D VAE decode.
+"""Functional CPU restatement of the causal-3D VAE: decode, and the encode half behind `vae_encode`.
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).
 
@@ -12,6 +12,9 @@ from its published algorithm (each marked `[diffusers, unpinned]`); nothing in t
 container can confirm them.  What the GPU tests therefore establish is that the HIP
 decoder computes THIS algorithm; the first time the real package or real VAE weights
 are available, `strict` state-dict loading and a decode comparison must re-check it.
+
+The encode half (ref: diffusers_helper/hunyuan.py:107-110 `vae_encode`: `vae.encode(image).latent_dist.sample()`
+times scaling_factor; called on single images, ref: framepack/worker.py:246-272) is restated under the same terms.
 
 `P` is a flat state dict with diffusers' parameter names (`decoder.conv_in.conv.weight`,
 `decoder.up_blocks.0.resnets.0.norm1.weight`, `post_quant_conv.weight`, ...), volumes
@@ -65,13 +68,13 @@ def up_block_plan(cfg: VAEConfig) -> List[Tuple[int, int, Tuple[int, int, int] |
     return plan
 
 
-def causal_conv3d(P: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
+def causal_conv3d(P: Dict[str, Tensor], name: str, x: Tensor, stride: Tuple[int, int, int] = (1, 1, 1)) -> Tensor:
     """[diffusers, unpinned] HunyuanVideoCausalConv3d: replicate padding, (k-1) frames in front and none
-    behind in time, k//2 on each side in space; then a plain Conv3d (weights at `<name>.conv`)."""
+    behind in time, k//2 on each side in space; then a plain (optionally strided) Conv3d (weights at `<name>.conv`)."""
     w = P[name + ".conv.weight"]
     kt, kh, kw = w.shape[2:]
     x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0), mode="replicate")
-    return F.conv3d(x, w, P.get(name + ".conv.bias"))
+    return F.conv3d(x, w, P.get(name + ".conv.bias"), stride=stride)
 
 
 def group_norm(P: Dict[str, Tensor], name: str, x: Tensor, groups: int, eps: float = 1e-6) -> Tensor:
@@ -191,8 +194,65 @@ def vae_decode(P: Dict[str, Tensor], cfg: VAEConfig, latents: Tensor, framewise:
     return decode(P, cfg, latents / cfg.scaling_factor, framewise)
 
 
-def random_state_dict(cfg: VAEConfig, seed: int = 0, dtype: torch.dtype = torch.float32) -> Dict[str, Tensor]:
-    """Seeded random decoder weights with diffusers' names (no checkpoint exists offline)."""
+# ---------------------------------------------------------------------------------------------------- encode half
+def down_block_plan(cfg: VAEConfig) -> List[Tuple[int, int, Tuple[int, int, int] | None]]:
+    """[diffusers, unpinned] HunyuanVideoEncoder3D.__init__: (in_ch, out_ch, downsample stride or None) per down
+    block.  With ratios 8 / 4 and four blocks: block 0 strides (1,2,2), blocks 1 and 2 (2,2,2), block 3 nothing."""
+    import math
+    ch = cfg.block_out_channels
+    n = len(ch)
+    n_sp = int(math.log2(cfg.spatial_compression_ratio))
+    n_t = int(math.log2(cfg.temporal_compression_ratio))
+    plan = []
+    out_ch = ch[0]
+    for i in range(n):
+        prev, out_ch = out_ch, ch[i]
+        final = i == n - 1
+        sp = i < n_sp
+        tm = (i >= n - 1 - n_t) and not final
+        plan.append((prev, out_ch, ((2 if tm else 1), (2 if sp else 1), (2 if sp else 1)) if (sp or tm) else None))
+    return plan
+
+
+def encoder(P: Dict[str, Tensor], cfg: VAEConfig, x: Tensor) -> Tensor:
+    """[diffusers, unpinned] HunyuanVideoEncoder3D.forward: conv_in, down blocks (resnets, then a strided causal
+    conv), mid block, GroupNorm + SiLU, conv_out to 2 x latent channels."""
+    g = cfg.norm_num_groups
+    h = causal_conv3d(P, "encoder.conv_in", x)
+    for i, (_, _, stride) in enumerate(down_block_plan(cfg)):
+        for j in range(cfg.layers_per_block):
+            h = resnet_block(P, f"encoder.down_blocks.{i}.resnets.{j}", h, g)
+        if stride is not None:
+            h = causal_conv3d(P, f"encoder.down_blocks.{i}.downsamplers.0.conv", h, stride)
+    h = resnet_block(P, "encoder.mid_block.resnets.0", h, g)
+    if cfg.mid_block_add_attention:
+        h = mid_attention(P, "encoder.mid_block.attentions.0", h, g)
+    h = resnet_block(P, "encoder.mid_block.resnets.1", h, g)
+    h = F.silu(group_norm(P, "encoder.conv_norm_out", h, g))
+    return causal_conv3d(P, "encoder.conv_out", h)
+
+
+def encode_moments(P: Dict[str, Tensor], cfg: VAEConfig, x: Tensor) -> Tuple[Tensor, Tensor]:
+    """[diffusers, unpinned] AutoencoderKLHunyuanVideo.encode without tiling (inputs of at most 16 frames; the
+    reference encodes single images): encoder, quant_conv (1x1x1), then DiagonalGaussianDistribution's
+    (mean, logvar clamped to [-30, 20])."""
+    m = F.conv3d(encoder(P, cfg, x), P["quant_conv.weight"], P["quant_conv.bias"])
+    mean, logvar = m.chunk(2, dim=1)
+    return mean, logvar.clamp(-30.0, 20.0)
+
+
+def vae_encode(P: Dict[str, Tensor], cfg: VAEConfig, image: Tensor, noise: Tensor | None) -> Tensor:
+    """ref: diffusers_helper/hunyuan.py:107-110.  `latent_dist.sample()` = mean + exp(logvar / 2) * noise; the noise
+    is an argument here (None = the mode) so that a test can feed both sides the same draw."""
+    mean, logvar = encode_moments(P, cfg, image)
+    z = mean if noise is None else mean + torch.exp(0.5 * logvar) * noise
+    return z * cfg.scaling_factor
+
+
+def random_state_dict(cfg: VAEConfig, seed: int = 0, dtype: torch.dtype = torch.float32,
+                      with_encoder: bool = False, in_channels: int = 3) -> Dict[str, Tensor]:
+    """Seeded random weights with diffusers' names (no checkpoint exists offline).  The encoder half is drawn
+    after the decoder half, so the decoder weights of a seed do not depend on `with_encoder`."""
     g = torch.Generator().manual_seed(seed)
     P: Dict[str, Tensor] = {}
 
@@ -233,4 +293,20 @@ def random_state_dict(cfg: VAEConfig, seed: int = 0, dtype: torch.dtype = torch.
             conv(f"decoder.up_blocks.{i}.upsamplers.0.conv.conv", cout, cout, 3)
     norm("decoder.conv_norm_out", cfg.block_out_channels[0])
     conv("decoder.conv_out.conv", cfg.block_out_channels[0], cfg.out_channels, 3)
+    if with_encoder:
+        conv("encoder.conv_in.conv", in_channels, cfg.block_out_channels[0], 3)
+        for i, (cin, cout, stride) in enumerate(down_block_plan(cfg)):
+            for j in range(cfg.layers_per_block):
+                resnet(f"encoder.down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout)
+            if stride is not None:
+                conv(f"encoder.down_blocks.{i}.downsamplers.0.conv.conv", cout, cout, 3)
+        resnet("encoder.mid_block.resnets.0", top, top)
+        a = "encoder.mid_block.attentions.0"
+        norm(a + ".group_norm", top)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(a + "." + n, top, top)
+        resnet("encoder.mid_block.resnets.1", top, top)
+        norm("encoder.conv_norm_out", top)
+        conv("encoder.conv_out.conv", top, 2 * cfg.latent_channels, 3)
+        conv("quant_conv", 2 * cfg.latent_channels, 2 * cfg.latent_channels, 1)
     return P

@@ -123,25 +123,37 @@ def test_bad_rank_raises_value_error(tiny_model):
 
 # ---------------------------------------------------------------- VAE decode boundary (host logic, no GPU)
 def test_vae_state_dict_names_and_plan_match_oracle_layout():
-    from framepack_amd.vae import AutoencoderKLHunyuanVideo, _up_block_plan
+    from framepack_amd.vae import AutoencoderKLHunyuanVideo, _down_block_plan, _up_block_plan
     from oracle import vae_oracle as VO
     cfg = VO.VAEConfig()
     vae = AutoencoderKLHunyuanVideo()
-    want = VO.random_state_dict(VO.VAEConfig(block_out_channels=(32, 32, 64, 64)))      # names only (small)
+    small_cfg = VO.VAEConfig(block_out_channels=(32, 32, 64, 64))
+    want = VO.random_state_dict(small_cfg, with_encoder=True)                             # names only (small)
     small = AutoencoderKLHunyuanVideo(block_out_channels=(32, 32, 64, 64))
     assert set(small.state_dict().keys()) == set(want.keys())
     assert {k: tuple(v.shape) for k, v in small.state_dict().items()} == {k: tuple(v.shape) for k, v in want.items()}
     assert _up_block_plan(cfg.block_out_channels, 8, 4) == VO.up_block_plan(cfg) == [
         (512, 512, (1, 2, 2)), (512, 512, (2, 2, 2)), (512, 256, (2, 2, 2)), (256, 128, None)]
+    assert _down_block_plan(cfg.block_out_channels, 8, 4) == VO.down_block_plan(cfg) == [
+        (128, 128, (1, 2, 2)), (128, 256, (2, 2, 2)), (256, 512, (2, 2, 2)), (512, 512, None)]
     assert vae.config.scaling_factor == 0.476986 and vae.use_framewise_decoding
-    # a full checkpoint also carries the encode half: those keys are ignored, the decode half stays strict
-    sd = dict(small.state_dict())
-    sd["encoder.conv_in.conv.weight"] = torch.zeros(1)
-    sd["quant_conv.weight"] = torch.zeros(1)
-    small.load_state_dict(sd, strict=True)
-    del sd["decoder.conv_out.conv.bias"]
+    # a full checkpoint loads strictly into both halves; a decoder-only one strictly into the decode half
+    small.load_state_dict(want, strict=True)
+    assert small._encoder_loaded
+    dec_only = VO.random_state_dict(small_cfg)
+    assert not any(k.startswith("encoder.") or k.startswith("quant_conv.") for k in dec_only)
+    small.load_state_dict(dec_only, strict=True)
+    assert not small._encoder_loaded
     with pytest.raises(RuntimeError):
-        small.load_state_dict(sd, strict=True)
+        small.encode(torch.zeros(1, 3, 1, 64, 64))                    # CPU tensor (and no encoder weights)
+    for broken in (dict(dec_only), dict(want)):
+        del broken["decoder.conv_out.conv.bias"]
+        with pytest.raises(RuntimeError):
+            small.load_state_dict(broken, strict=True)
+    half = dict(want)
+    del half["encoder.conv_out.conv.bias"]                            # an encoder half must be complete too
+    with pytest.raises(RuntimeError):
+        small.load_state_dict(half, strict=True)
 
 
 def test_vae_decode_refuses_cpu_and_preview_matches_projection():

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from framepack_amd import ops  # noqa: E402
-from framepack_amd.vae import AutoencoderKLHunyuanVideo, vae_decode  # noqa: E402
+from framepack_amd.vae import AutoencoderKLHunyuanVideo, vae_decode, vae_encode  # noqa: E402
 from oracle import vae_oracle as VO  # noqa: E402
 
 DEV = "cuda:0"
@@ -73,6 +73,25 @@ def test_conv3d_causal(T, H, W, cin, cout, up, with_res):
     torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("T,H,W,cin,cout,stride", [
+    (1, 16, 16, 64, 64, (1, 2, 2)),               # the single-image case: every temporal tap clamps to frame 0
+    (5, 12, 10, 64, 72, (2, 2, 2)),               # 5 -> 3 frames
+    (4, 9, 7, 128, 64, (2, 2, 2)),                # even T (4 -> 2) and odd H, W (9 -> 5, 7 -> 4): upper clamps
+    (3, 6, 6, 64, 128, (2, 1, 1)),                # temporal stride only
+    (3, 40, 40, 64, 256, (1, 2, 2)),              # several M tiles
+])
+def test_conv3d_causal_strided(T, H, W, cin, cout, stride):
+    x = rand(T, H, W, cin, seed=1)
+    w = rand(cout, cin, 3, 3, 3, seed=2, scale=(27 * cin) ** -0.5)
+    b = rand(cout, seed=3, scale=0.1)
+    xr = x.float().permute(3, 0, 1, 2).unsqueeze(0)
+    ref = VO.causal_conv3d({"c.conv.weight": w.float(), "c.conv.bias": b.float()}, "c", xr, stride)[0].permute(1, 2, 3, 0)
+    got = ops.conv3d_causal_strided(x.to(DEV), prep_w(w).to(DEV), b.to(DEV), stride)
+    assert got.dtype == H16 and tuple(got.shape) == tuple(ref.shape)
+    assert rel_l2(got, ref) < 2e-3
+    torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+
+
 def test_conv3d_rejects_bad_arguments():
     x, w = rand(2, 4, 4, 32).to(DEV), rand(64, 27 * 32).to(DEV)
     with pytest.raises(ValueError):
@@ -117,9 +136,9 @@ def test_gemm_f16_bias_and_residual():
 SMALL = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=16)
 
 
-def build(cfg_kw, seed=0):
+def build(cfg_kw, seed=0, with_encoder=False):
     cfg = VO.VAEConfig(**cfg_kw)
-    P = VO.random_state_dict(cfg, seed=seed)
+    P = VO.random_state_dict(cfg, seed=seed, with_encoder=with_encoder)
     P16 = {k: v.to(H16) for k, v in P.items()}
     vae = AutoencoderKLHunyuanVideo(**cfg_kw)
     vae.load_state_dict(P16, strict=True)
@@ -155,3 +174,45 @@ def test_image_mode_decodes_frames_independently():
     got = vae_decode(z.to(DEV), vae, image_mode=True)
     ref = torch.cat([VO.vae_decode(P, cfg, z[:, :, i:i + 1].to(H16).float()) for i in range(2)], dim=2)
     assert tuple(got.shape) == (1, 3, 2, 48, 48) and psnr(got, ref) >= 40.0
+
+
+# ------------------------------------------------------------------ encode half (vae_encode)
+@pytest.mark.parametrize("T,H,W", [(1, 64, 64), (1, 48, 80), (5, 32, 32)])
+def test_encoder_moments_match_oracle(T, H, W):
+    cfg, P, vae = build(SMALL, seed=3, with_encoder=True)
+    x = torch.rand(1, 3, T, H, W, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    mean, logvar = VO.encode_moments(P, cfg, x.to(H16).float())
+    dist = vae.encode(x.to(DEV, H16)).latent_dist
+    To = 1 + (T - 1) // 4 if T > 1 else 1
+    assert tuple(dist.mean.shape) == tuple(mean.shape) == (1, 16, mean.shape[2], H // 8, W // 8) and dist.mean.dtype == H16
+    assert rel_l2(dist.mean, mean) < 1e-2 and rel_l2(dist.logvar, logvar) < 1e-2
+    assert rel_l2(dist.std, torch.exp(0.5 * logvar)) < 1e-2
+    assert torch.equal(dist.mode(), dist.mean)
+
+
+def test_vae_encode_samples_with_the_given_noise_and_scales():
+    cfg, P, vae = build(SMALL, seed=4, with_encoder=True)
+    x = torch.rand(1, 3, 1, 64, 64, generator=torch.Generator().manual_seed(7)) * 2 - 1
+    torch.manual_seed(11)
+    got = vae_encode(x, vae)                                          # moves to vae.device / vae.dtype itself
+    torch.manual_seed(11)
+    noise = torch.randn(1, 16, 1, 8, 8, device=DEV, dtype=H16)       # the draw latent_dist.sample() made
+    ref = VO.vae_encode(P, cfg, x.to(H16).float(), noise.float().cpu())
+    assert got.dtype == H16 and tuple(got.shape) == (1, 16, 1, 8, 8)
+    assert rel_l2(got, ref) < 1e-2
+    # encode -> decode round trip runs end to end through both halves
+    back = vae_decode(got, vae)
+    assert tuple(back.shape) == (1, 3, 1, 64, 64) and torch.isfinite(back).all()
+
+
+def test_encode_argument_checks_and_decoder_only_checkpoints():
+    cfg, P, vae = build(SMALL, seed=5, with_encoder=True)
+    with pytest.raises(RuntimeError):
+        vae.encode(torch.zeros(1, 3, 1, 64, 64, dtype=H16))           # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        vae.encode(torch.zeros(1, 3, 1, 60, 64, dtype=H16, device=DEV))
+    with pytest.raises(ValueError):
+        vae.encode(torch.zeros(1, 3, 17, 64, 64, dtype=H16, device=DEV))
+    _, _, dec_only = build(SMALL, seed=5)
+    with pytest.raises(RuntimeError, match="decoder-only"):
+        dec_only.encode(torch.zeros(1, 3, 1, 64, 64, dtype=H16, device=DEV))

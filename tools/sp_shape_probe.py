@@ -1,0 +1,59 @@
+"""Per-rank compute of one DiT step under Ulysses sequence parallelism, emulated on ONE GPU: the GEMMs at the rank's
+row count and the attention at the rank's head count (the exchange itself is not in here).
+usage: sp_shape_probe.py [P ...]"""
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from framepack_amd import ops  # noqa: E402
+
+dev = "cuda:0"
+S, d = 19385, 3072
+g = torch.Generator(device=dev).manual_seed(0)
+
+
+def rnd(*shape, scale=1.0):
+    return (torch.randn(*shape, generator=g, device=dev) * scale).to(torch.bfloat16)
+
+
+def timed(fn, n=8):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+W = {n: rnd(n, k, scale=k ** -0.5) for n, k in ((21504, 3072), (9216, 3072), (12288, 3072))}
+W[(3072, 15360)] = rnd(3072, 15360, scale=15360 ** -0.5)
+W[(3072, 12288)] = rnd(3072, 12288, scale=12288 ** -0.5)
+W[(3072, 3072)] = rnd(3072, 3072, scale=3072 ** -0.5)
+bias = {n: rnd(n) for n in (21504, 9216, 12288, 3072)}
+base = None
+for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    n = math.ceil(S / P)
+    x3, x15, x12 = rnd(n, 3072), rnd(n, 15360), rnd(n, 12288)
+    res = rnd(n, 3072)
+    o21, o9, o12, o3 = (torch.empty(n, k, dtype=torch.bfloat16, device=dev) for k in (21504, 9216, 12288, 3072))
+    t = {}
+    t["in-proj x40"] = 40 * timed(lambda: ops.gemm(x3, W[21504], bias[21504], out=o21, epilogue=2, gelu_from=9216))
+    t["out-proj x40"] = 40 * timed(lambda: ops.gemm(x15, W[(3072, 15360)], bias[3072], out=o3, epilogue=3, resid=res, gate=bias[3072]))
+    t["qkv x20"] = 20 * timed(lambda: ops.gemm(x3, W[9216], bias[9216], out=o9))
+    t["attn-out x20"] = 20 * timed(lambda: ops.gemm(x3, W[(3072, 3072)], bias[3072], out=o3, epilogue=3, resid=res, gate=bias[3072]))
+    t["ff1 x20"] = 20 * timed(lambda: ops.gemm(x3, W[12288], bias[12288], out=o12, epilogue=1))
+    t["ff2 x20"] = 20 * timed(lambda: ops.gemm(x12, W[(3072, 12288)], bias[3072], out=o3, epilogue=3, resid=res, gate=bias[3072]))
+    h = 24 // P
+    q, k, v = rnd(S, h * 128), rnd(S, h * 128), rnd(S, h * 128)
+    t["attention x60"] = 60 * timed(lambda: ops.attention(q, k, v, h), n=4)
+    tot = sum(t.values())
+    base = base or tot * P
+    print(f"P={P} rows/rank {n} heads/rank {h}: " + " | ".join(f"{k} {v:.1f}" for k, v in t.items()) +
+          f" | total {tot:.1f} ms = {base / P / tot * 100:.0f} % of ideal", flush=True)
