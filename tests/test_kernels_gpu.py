@@ -159,6 +159,43 @@ def test_gemm_strided_two_segment_and_inplace_residual(gemm_variant):
     assert rel_l2(xd2, ref) < 4e-3
 
 
+@pytest.mark.parametrize("N,K,epi", [(21504, 3072, 2), (3072, 15360, 3), (9216, 3072, 0), (12288, 3072, 1)])
+def test_gemm_full_size_sampled_rows(N, K, epi):
+    """The model's GEMM shapes at the BASELINE config 2 row count (S = 19385: 76 row tiles, the last one ragged, more
+    tiles than CUs so the persistent workgroups loop): sampled rows of every region of the output against fp64, plus
+    a size-independent property - doubling A doubles the linear part exactly (powers of two commute with rounding)."""
+    M = 19385
+    g = torch.Generator(device=DEV).manual_seed(7)
+    a = torch.randn(M, K, generator=g, device=DEV).to(BF)
+    w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(BF)
+    b = torch.randn(N, generator=g, device=DEV).to(BF)
+    kw, gf = {}, 0
+    if epi == 2:
+        gf = 9216
+        kw = dict(gelu_from=gf)
+    if epi == 3:
+        r, gate = torch.randn(M, N, generator=g, device=DEV).to(BF), torch.randn(N, generator=g, device=DEV).to(BF)
+        kw = dict(resid=r, gate=gate)
+    got = ops.gemm(a, w, b, epilogue=epi, **kw)
+    rows = torch.tensor([0, 1, 127, 128, 255, 256, 4095, 9999, 19199, 19200, 19328, 19383, 19384], device=DEV)
+    lin = (a[rows].double() @ w.double().T + b.double()).cpu()
+    gelu = torch.nn.functional.gelu(lin, approximate="tanh")
+    if epi == 0:
+        ref = lin
+    elif epi == 1:
+        ref = gelu
+    elif epi == 2:
+        ref = torch.cat([lin[:, :gf], gelu[:, gf:]], dim=1)
+    else:
+        ref = r[rows].double().cpu() + gate.double().cpu() * lin
+    assert rel_l2(got[rows], ref) < 4e-3
+    torch.testing.assert_close(got[rows].double().cpu(), ref, rtol=2e-2, atol=2e-2)
+    if epi == 0:
+        got2 = ops.gemm(a * 2, w, None)
+        got1 = ops.gemm(a, w, None)
+        assert torch.equal(got2, got1 * 2)
+
+
 def test_gemm_rejects_bad_arguments():
     a, w = randn(4, 100, seed=1).to(DEV), randn(8, 100, seed=2).to(DEV)   # K % 64 != 0
     with pytest.raises(ValueError):
