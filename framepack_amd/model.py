@@ -283,6 +283,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
         self._sp_total = 0
         self.fp8_compute = False       # block linears on the fp8 MFMA (enable_fp8_compute)
+        self.fp8_attention = False     # joint attention with e4m3 Q, K, P, V (enable_fp8_attention)
 
     # ---- reference API ---------------------------------------------------------------------
     def install_image_projection(self, in_channels):
@@ -358,14 +359,22 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ws = {}
         return self
 
+    def enable_fp8_attention(self, enable: bool = True):
+        """Opt-in: the joint attention of every block with Q, K, P and V in e4m3 (`fp_attn_fwd_fp8`; the role the
+        reference gives its quantised SageAttention branch, hunyuan_video_packed.py:92-94).  A few per cent away
+        from the bf16 result: outside the 1e-2 parity bar, never on by default."""
+        self.fp8_attention = bool(enable)
+        return self
+
     def _attend(self, q, k, v, n_img):
         """Joint attention over [image rows | text rows]; output written over q."""
+        attn = ops.attention_fp8 if self.fp8_attention else ops.attention
         if self.sp_world == 1:
-            ops.attention(q, k, v, self.heads, out=q)
+            attn(q, k, v, self.heads, out=q)
         else:
             from .ulysses import ulysses_attention
             ulysses_attention(q, k, v, self._sp_total, self.heads, self.head_dim,
-                              lambda jq, jk, jv, h, o: ops.attention(jq, jk, jv, h, out=o), self.sp_group, out=q)
+                              lambda jq, jk, jv, h, o: attn(jq, jk, jv, h, out=o), self.sp_group, out=q)
 
     @property
     def device(self):

@@ -150,6 +150,43 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out
     return out
 
 
+_ATTN_FP8_WS = {}
+
+
+def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
+                  scale: Optional[float] = None) -> torch.Tensor:
+    """K1, fp8 variant (opt-in): one segment, Q / K / P / V in e4m3 on the fp8 MFMA; q, k, v as for `attention`
+    (bf16; quantised inside the call).  A few per cent away from the bf16 kernel.  out may alias q."""
+    _dev(q, k, v, out)
+    q2, rows, cols, qs = _rows2d(q)
+    k2, _, _, ks = _rows2d(k)
+    v2, _, _, vs = _rows2d(v)
+    assert cols == heads * 128 and k2.shape == q2.shape and v2.shape == q2.shape
+    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16
+    if out is None:
+        out = torch.empty((rows, cols), dtype=BF16, device=q.device)
+    o2, orows, ocols, os_ = _rows2d(out)
+    assert (orows, ocols) == (rows, cols) and out.dtype == BF16
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    lib = _lib.load()
+    need = lib.fp_attn_fp8_workspace_bytes(rows, heads)
+    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+    ws = _ATTN_FP8_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _ATTN_FP8_WS[key] = torch.empty((max(need, 256),), dtype=torch.uint8, device=q.device)
+    ev = None
+    if ATTN_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(q.device))
+    _lib.check(lib.fp_attn_fwd_fp8(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o2.data_ptr(), qs, ks, vs, os_, rows,
+                                   heads, 128, scale, ws.data_ptr(), ws.numel(), _stream(q)), "fp_attn_fwd_fp8")
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(q.device))
+        ATTN_EVENTS.append((ev[0], ev[1], rows, heads))
+    return out
+
+
 def silu_gemv(t: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], apply_silu: bool = True,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K7: Linear(SiLU(t)) for a single vector t [in]; weight [out, in]."""

@@ -1,0 +1,101 @@
+"""K1 fp8 variant (fp_attn_fwd_fp8): e4m3 Q, K, P, V on the fp8 MFMA.  Opt-in and OUTSIDE the 1e-2 parity bar of the
+SDPA path: what is pinned here is (a) that the kernel computes attention of its own quantised operands - against an
+fp64 reference built from the same e4m3 values (torch's float8_e4m3fn cast as the quantiser), where only the e4m3
+rounding of P separates the two - and (b) the measured distance to the unquantised result, asserted loosely and
+printed."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from framepack_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+BF = torch.bfloat16
+E4 = torch.float8_e4m3fn
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rand_qkv(S, heads, seed):
+    g = torch.Generator("cpu").manual_seed(seed)
+    d = heads * 128
+    q = torch.randn(S, d, generator=g)
+    k = torch.randn(S, d, generator=g)
+    v = torch.randn(S, d, generator=g) * (0.25 + torch.rand(d, generator=g) * 4)      # channels of different size
+    return q.to(BF), k.to(BF), v.to(BF)
+
+
+def dequantised(q, k, v, heads):
+    """The operands as the kernel sees them: per-head scales for q and k, per-(head, channel) for v."""
+    S = q.shape[0]
+    qh, kh = q.float().view(S, heads, 128), k.float().view(S, heads, 128)
+    sq = qh.abs().amax(dim=(0, 2), keepdim=True) * (1.0 / 448.0)
+    sk = kh.abs().amax(dim=(0, 2), keepdim=True) * (1.0 / 448.0)
+    sv = v.float().abs().amax(dim=0, keepdim=True) * (1.0 / 448.0)
+    sq, sk, sv = (torch.where(s > 0, s, torch.ones_like(s)) for s in (sq, sk, sv))
+    dq = ((qh * (1.0 / sq)).to(E4).float() * sq).view(S, -1)
+    dk = ((kh * (1.0 / sk)).to(E4).float() * sk).view(S, -1)
+    dv = (v.float() / sv).to(E4).float() * sv
+    return dq, dk, dv
+
+
+def attn64(q, k, v, heads):
+    S = q.shape[0]
+    qh, kh, vh = (x.double().view(S, heads, 128).transpose(0, 1) for x in (q, k, v))
+    p = torch.softmax(qh @ kh.transpose(1, 2) / math.sqrt(128.0), dim=-1)
+    return (p @ vh).transpose(0, 1).reshape(S, -1)
+
+
+@pytest.mark.parametrize("S,heads", [(1, 1), (63, 2), (64, 1), (65, 3), (256, 2), (300, 1), (777, 3), (2174, 2)])
+def test_fp8_attention_of_its_own_quantised_operands(S, heads):
+    q, k, v = rand_qkv(S, heads, seed=S)
+    got = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    dq, dk, dv = dequantised(q, k, v, heads)
+    ref = attn64(dq, dk, dv, heads)
+    assert got.dtype == BF and tuple(got.shape) == (S, heads * 128) and torch.isfinite(got.float()).all()
+    # only P's e4m3 rounding (relative 2^-4 per weight, independent across keys) and bf16 output rounding remain
+    assert rel_l2(got, ref) < 3e-2, rel_l2(got, ref)
+
+
+def test_fp8_attention_distance_to_unquantised_and_to_bf16_kernel():
+    S, heads = 2174, 3
+    q, k, v = rand_qkv(S, heads, seed=5)
+    got = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    exact = attn64(q, k, v, heads)
+    bf = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    d_exact, d_bf = rel_l2(got, exact), rel_l2(got, bf)
+    print(f"fp8 attention vs fp64 attention of the bf16 operands: rel-L2 {d_exact:.4f}; vs the bf16 kernel: {d_bf:.4f}")
+    assert rel_l2(bf, exact) < 5e-3
+    assert d_exact < 8e-2
+
+
+def test_fp8_attention_constant_values_strided_views_and_aliasing():
+    S, heads = 1000, 2
+    d = heads * 128
+    q, k, v = rand_qkv(S, heads, seed=9)
+    # V = per-channel constant: the output is that constant up to P's rounding in the normalisation
+    vc = (torch.arange(d).float() * 0.01 - 1.0).to(BF).expand(S, d).contiguous()
+    o1 = ops.attention_fp8(q.to(DEV), k.to(DEV), vc.to(DEV), heads)
+    assert (o1.float().cpu() - vc.float()).abs().max().item() < 0.03 * vc.float().abs().max().item() + 1e-2
+    # q | k | v as column ranges of one row-strided buffer, output over q (the model's layout)
+    buf = torch.cat([q, k, v, torch.zeros(S, 64, dtype=BF)], dim=1).to(DEV)
+    want = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    got = ops.attention_fp8(buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d], heads, out=buf[:, :d])
+    assert got.data_ptr() == buf.data_ptr() and torch.equal(buf[:, :d], want)
+    assert torch.equal(buf[:, d:3 * d].cpu(), torch.cat([k, v], dim=1))            # k, v untouched
+    again = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert torch.equal(again, want)                                                 # deterministic
+
+
+def test_fp8_attention_rejects_bad_arguments():
+    q = torch.zeros(8, 128, dtype=BF, device=DEV)
+    with pytest.raises(AssertionError):
+        ops.attention_fp8(q, q, q, 2)                                               # 2 heads need 256 columns
+    with pytest.raises(RuntimeError):
+        ops.attention_fp8(q.cpu(), q.cpu(), q.cpu(), 1)                            # no CPU fallback

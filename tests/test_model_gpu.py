@@ -187,6 +187,30 @@ def test_fp8_compute_mode_tracks_bf16_and_switches_off_cleanly():
     assert torch.equal(again, base)
 
 
+def test_fp8_attention_mode_tracks_bf16_and_switches_off_cleanly():
+    """enable_fp8_attention(): the joint attention of every block on the fp8 MFMA (e4m3 Q, K, P, V).  Not a parity
+    path; it has to track the bf16 result to quantisation accuracy and switch off bit for bit."""
+    m, _ = build(synthetic.CONFIG_TINY)
+    kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES["config1"]))
+    m.taps = {}
+    base = m(return_dict=False, **kw)[0]
+    taps16 = m.taps
+    m.enable_fp8_attention()
+    m.taps = {}
+    got = m(return_dict=False, **kw)[0]
+    taps8, m.taps = m.taps, None
+    worst = 0.0
+    for name in taps16:
+        if name.startswith(("double.", "single.")):
+            for a, b in zip(taps8[name], taps16[name]):
+                worst = max(worst, rel_l2(a, b))
+    d = rel_l2(got, base)
+    print(f"fp8 attention vs bf16: worst block rel-L2 {worst:.4f}, output rel-L2 {d:.4f}")
+    assert 1e-4 < worst < 8e-2 and 1e-4 < d < 0.12
+    m.enable_fp8_attention(False)
+    assert torch.equal(m(return_dict=False, **kw)[0], base)
+
+
 def test_fp8_compute_mode_uses_reference_checkpoint_bytes_and_scales():
     """With a reference fp8 checkpoint (e4m3 weight + per-tensor scale_weight) the fp8-compute path multiplies by
     exactly those bytes: the only difference to the W8A16 path is the activation quantisation."""

@@ -21,14 +21,15 @@ if os.environ.get("LAYOUT", "fused") == "fused":
 else:
     k, v, q = (torch.randn(S, d, generator=g, device=dev).to(torch.bfloat16) for _ in range(3))
 out = torch.empty(S, d, dtype=torch.bfloat16, device=dev)
+attn = ops.attention_fp8 if os.environ.get("FP8") else ops.attention       # FP8=1: the e4m3 variant (quantisation included)
 for variant in range(int(os.environ.get("REPEAT", "2"))):
     for _ in range(3):
-        ops.attention(q, k, v, H, out=out)
+        attn(q, k, v, H, out=out)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(iters):
-        ops.attention(q, k, v, H, out=out)
+        attn(q, k, v, H, out=out)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / iters
