@@ -39,13 +39,14 @@ __host__ __device__ __forceinline__ int slot_key(int p) {
 }
 
 // ---- quantisation -----------------------------------------------------------------------------------------------
-// column-wise |max| of q, k and v over all rows: amax[3][C] (uint bit patterns of non-negative floats order like the
-// floats, so the merge is an integer atomic max).  Block = 32 rows x 256 chunks of 8 columns (grid.y walks the chunks
-// of the three tensors): one chunk per thread, rows read as 4 KiB runs per wave.
+// column-wise |max| of q, k and v over all rows, in two deterministic stages without atomics (606 row blocks
+// hammering 9216 addresses with atomic max took longer than reading the data): partial[row block][3][C], then
+// amax[3][C].  Block = 32 rows x 256 chunks of 8 columns (grid.y walks the chunks of the three tensors): one
+// chunk per thread, rows read as 4 KiB runs per wave.
 constexpr int AMAX_ROWS = 32;
 __global__ __launch_bounds__(256) void absmax_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k,
                                                      const bf16* __restrict__ v, int64_t q_rs, int64_t k_rs,
-                                                     int64_t v_rs, int S, int C, unsigned* __restrict__ amax) {
+                                                     int64_t v_rs, int S, int C, float* __restrict__ partial) {
     const int r0 = blockIdx.x * AMAX_ROWS, r1 = min(r0 + AMAX_ROWS, S);
     const int nch = C / 8;
     const int item = blockIdx.y * 256 + threadIdx.x;
@@ -54,23 +55,34 @@ __global__ __launch_bounds__(256) void absmax_kernel(const bf16* __restrict__ q,
     const bf16* base = (which == 0 ? q : (which == 1 ? k : v)) + c * 8;
     const int64_t rs = which == 0 ? q_rs : (which == 1 ? k_rs : v_rs);
     float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) {
         const bf16x8 x = *reinterpret_cast<const bf16x8*>(base + (int64_t)r * rs);
 #pragma unroll
         for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], fabsf((float)x[j]));
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) atomicMax(amax + which * C + c * 8 + j, __float_as_uint(m[j]));
+    float* out = partial + (int64_t)blockIdx.x * 3 * C + which * C + c * 8;
+    *reinterpret_cast<f32x4*>(out) = f32x4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<f32x4*>(out + 4) = f32x4{m[4], m[5], m[6], m[7]};
+}
+
+__global__ __launch_bounds__(256) void absmax_reduce_kernel(const float* __restrict__ partial, int nblk, int n,
+                                                            float* __restrict__ amax) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float m = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nblk; ++b) m = fmaxf(m, partial[(int64_t)b * n + i]);
+    amax[i] = m;
 }
 
 // scales[0..H) = sq, [H..2H) = sk, [2H..2H+128H) = sv  (amax / 448; 1 where the amax is 0)
-__global__ __launch_bounds__(128) void scales_kernel(const unsigned* __restrict__ amax, int heads,
+__global__ __launch_bounds__(128) void scales_kernel(const float* __restrict__ amax, int heads,
                                                      float* __restrict__ scales) {
     __shared__ float red[2][2];
     const int h = blockIdx.x, d = threadIdx.x, C = heads * HD;
-    float mq = __uint_as_float(amax[h * HD + d]), mk = __uint_as_float(amax[C + h * HD + d]);
-    const float mv = __uint_as_float(amax[2 * C + h * HD + d]);
+    float mq = amax[h * HD + d], mk = amax[C + h * HD + d];
+    const float mv = amax[2 * C + h * HD + d];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         mq = fmaxf(mq, __shfl_xor(mq, o, 64));
@@ -374,13 +386,14 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
 }  // namespace
 
 // Bytes of the quantised operands for S tokens: q8 + k8 (S*heads*128 each), vt8 (heads * ceil(S/64) * 8192),
-// scales (fp32: 2*heads + 128*heads) and the column-amax scratch (3*heads*128 uint).  Layout inside the buffer, in
-// this order, every part 256-byte aligned.
+// scales (fp32: 2*heads + 128*heads), the column amax (3*heads*128 fp32) and its per-row-block partials.  Layout
+// inside the buffer, in this order, every part 256-byte aligned.
 static int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 extern "C" int64_t fp_attn_fp8_workspace_bytes(int total_tokens, int heads) {
     const int64_t C = (int64_t)heads * HD, nt = (total_tokens + KVBLK - 1) / KVBLK;
+    const int64_t nblk = (total_tokens + AMAX_ROWS - 1) / AMAX_ROWS;
     return 2 * align256((int64_t)total_tokens * C) + align256(heads * nt * TILE_BYTES) + align256((2 * heads + C) * 4) +
-           align256(3 * C * 4);
+           align256(3 * C * 4) + align256(nblk * 3 * C * 4);
 }
 
 extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
@@ -406,12 +419,14 @@ extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void
     p += align256((int64_t)heads * nt * TILE_BYTES);
     float* scales = (float*)p;
     p += align256((2 * heads + C) * 4);
-    unsigned* amax = (unsigned*)p;
-
-    hipError_t e = hipMemsetAsync(amax, 0, (size_t)3 * C * 4, st);
-    if (e != hipSuccess) return (int)e;
-    absmax_kernel<<<dim3((unsigned)((S + AMAX_ROWS - 1) / AMAX_ROWS), (unsigned)((3 * C / 8 + 255) / 256)), dim3(256), 0, st>>>((const bf16*)q, (const bf16*)k, (const bf16*)v,
-                                                                        q_row_stride, k_row_stride, v_row_stride, S, C, amax);
+    float* amax = (float*)p;
+    p += align256(3 * C * 4);
+    float* partial = (float*)p;
+    const int nblk = (S + AMAX_ROWS - 1) / AMAX_ROWS;
+    absmax_kernel<<<dim3((unsigned)nblk, (unsigned)((3 * C / 8 + 255) / 256)), dim3(256), 0, st>>>(
+        (const bf16*)q, (const bf16*)k, (const bf16*)v, q_row_stride, k_row_stride, v_row_stride, S, C, partial);
+    FP_CHECK_LAUNCH();
+    absmax_reduce_kernel<<<dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, st>>>(partial, nblk, 3 * C, amax);
     FP_CHECK_LAUNCH();
     scales_kernel<<<dim3((unsigned)heads), dim3(128), 0, st>>>(amax, heads, scales);
     FP_CHECK_LAUNCH();
