@@ -59,7 +59,13 @@ template <int IDX> __device__ __forceinline__ f32x4 acc_read() {
     return f32x4{r0, r1, r2, r3};
 }
 
-template <typename T, typename TO, int EPI, int AMODE>
+// NT = 16-column tiles per wave (8 | 4 | 1): the workgroup's tile is 256 x (32 NT).  Narrow outputs (the VAE's
+// Cout = 128 and Cout = 3 layers, N <= 128 / N <= 32) take NT = 4 / 1: the two wave columns then share the real
+// columns instead of one wave column doing everything and the other only padding, and the MFMAs of the missing
+// tiles are not issued at all (compile-time: a run-time test per MFMA splits the loop into basic blocks and the
+// compiler then drains the memory counters at every join - measured, 20 % slower than doing the padding).  The
+// staging, the LDS reads and their slots are those of NT = 8.
+template <typename T, typename TO, int EPI, int AMODE, int NT = 8>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A, int64_t lda, int64_t a2_delta,
                                                          int k1, const T* __restrict__ W, int64_t ldw,
                                                          const TO* __restrict__ bias, TO* __restrict__ C,
@@ -99,12 +105,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             arow0[h][j] = (i >> 3) * 128 + h * 64 + (i & 7) * 8;
         }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wrow0[j] = (wave * 8 + j) * 8;
+    for (int j = 0; j < 8; ++j) wrow0[j] = (wave * NT + j) * 8;      // NT pieces per wave cover the tile's 32 NT rows of W
 
     // tile order: XCD-contiguous, grouped 8 row-tiles tall so that co-running tiles share A and W panels.  The
     // workgroup is persistent: it takes tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or
     // the whole tile count, so vb & 7 stays this workgroup's XCD).
     const int ntiles = ntm * ntn;
+    constexpr int CW = NT * 16;     // columns per wave column
+    unsigned a_rd[2], w_rd[2];  // fragment read addresses (below)
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr unsigned SECOND = SCALED ? 16u : 64u;
+    const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
     auto setup = [&](int vb) __attribute__((always_inline)) {
         constexpr int GM = 8;
         const int wid = xcd_remap(vb, ntiles);
@@ -114,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         const int gsz = min(ntm - first_m, GM);
         const int tm = first_m + in_group % gsz, tn = in_group / gsz;
         m0 = tm * BM;
-        n0 = tn * BN;
+        n0 = tn * (2 * CW);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -135,6 +146,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         }
         abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
         wbase = reinterpret_cast<const char*>(W + (int64_t)n0 * ldw);
+
     };
     const int nk = K / BKE;
     auto src_a = [&](int h, int j, int t) __attribute__((always_inline)) -> const T* {
@@ -170,31 +182,27 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         dma16(src_w(j, t), smem + W_BASE + (t & 1) * OP_BYTES + wrow0[j] * 128);
     };
 
-    // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (28 loads per wave)
+    // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (12 + 2 NT loads per wave)
     auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue_a1(0, j, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) issue_w1(j, 0);
+        for (int j = 0; j < NT; ++j) issue_w1(j, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue_a1(1, j, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) issue_a1(0, j, 1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) issue_w1(j, 1);
+        for (int j = 0; j < NT; ++j) issue_w1(j, 1);
     };
 
     // ---- fragment read offsets (as gemm_pipeline.h)
-    const int fr = lane & 15, fq = lane >> 4;
-    constexpr unsigned SECOND = SCALED ? 16u : 64u;
-    const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
     // One address register per K step and operand; every other offset - the buffer's included: the two A buffers
     // are neighbours, and so are the two W buffers - is an instruction immediate below 64 KiB.
-    unsigned a_rd[2], w_rd[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         a_rd[ks] = (unsigned)(wr * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
-        w_rd[ks] = W_BASE + (unsigned)(wc * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
+        w_rd[ks] = W_BASE + (unsigned)(wc * CW) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
         asm volatile("" : "+v"(a_rd[ks]), "+v"(w_rd[ks]));
     }
 
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0)
     auto mfma1 = [&](auto P, auto G, auto NI, auto ZC) __attribute__((always_inline)) {
         constexpr int MI = P * 4 + (G & 3);
-        mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0)>(wf[G >> 2][NI], af[G & 3]);
+        if constexpr (NI < NT) mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0)>(wf[G >> 2][NI], af[G & 3]);
     };
     // what is issued behind MFMA k of group g: at most one LDS read or one LDS-DMA per MFMA gap.
     //   P0(t) issues A-h1(t+1);  P1(t) issues A-h0(t+2) and W(t+2)  (W's fragments sit in registers after P0).
@@ -236,17 +244,18 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         } else {
             if constexpr (k == 2) {
                 if constexpr (g < 4) issue_a1(0, g, t + 2);
-                else issue_w1(g - 4, t + 2);
+                else if constexpr (g - 4 < NT) issue_w1(g - 4, t + 2);
             }
-            if constexpr (k == 5) issue_w1(2 + g, t + 2);
+            if constexpr (k == 5 && 2 + g < NT) issue_w1(2 + g, t + 2);
         }
     };
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     // relaxed: the 32 output stores of the previous tile may still be in flight behind the loads this phase needs
     // (memory operations retire in order), so the count that guarantees the loads is 16 + 32.
     auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed) __attribute__((always_inline)) {
-        if (relaxed) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // younger than the unit a phase needs are always 8 + NT pieces (4 of A-h0, 4 of A-h1, NT of W)
+        if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NT + 32) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NT) : "memory");
         __builtin_amdgcn_s_barrier();
         fence();
         if constexpr (P == 0) static_for<8>([&](auto ni) __attribute__((always_inline)) { rd_w(BUF, ic<0>{}, ni); });
@@ -284,9 +293,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         asm volatile("" : "+v"(l));
         return l;
     };
-    auto load_resid = [&](int em0, int en0, int mi) __attribute__((always_inline)) {
+    auto load_resid = [&](int em0, int en0, int ecw, int mi) __attribute__((always_inline)) {
         const int el = opaque_lane();
-        const int gcol = en0 + wc * 128 + (el & 15) * 8;
+        const int gcol = (el & 15) * 8 < ecw ? en0 + wc * ecw + (el & 15) * 8 : N;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = em0 + wr * 128 + mi * 16 + (el >> 4) + 4 * i;
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if (gcol < N && m < M) rpre[mi & 1][i] = *reinterpret_cast<const Tx8*>(R + (int64_t)m * ldr + gcol);
         }
     };
-    auto epilogue = [&](int em0, int en0) __attribute__((always_inline)) {
+    auto epilogue = [&](int em0, int en0, int ecw) __attribute__((always_inline)) {
         unsigned stage_off = 2 * BUF_BYTES + wave * 8192;      // opaque, so that the 4096 of the second stage buffer
         asm volatile("" : "+v"(stage_off));                    // stays an instruction immediate, not 12 more addresses
         unsigned char* stage = smem + stage_off;
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         f32x4 ws[8];
         const int el = opaque_lane();
         const int fr = el & 15, fq = el >> 4;                  // shadow the main loop's
-        const int nb = en0 + wc * 128 + 4 * fq;
+        const int nb = en0 + wc * ecw + 4 * fq;
 #pragma unroll
         for (int ni = 0; ni < 8; ++ni) {
             const int n = min(nb + ni * 16, N - 4);
@@ -312,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if (SCALED) ws[ni] = *reinterpret_cast<const f32x4*>(w_scale + n);
         }
         const int lrow = el >> 4, lchk = el & 15;
-        const int gcol = en0 + wc * 128 + lchk * 8;            // first of this lane's 8 columns in row layout
-        const bool col_ok = gcol < N;                          // N % 8 == 0: a chunk is inside or outside
+        const int gcol = en0 + wc * ecw + lchk * 8;            // first of this lane's 8 columns in row layout
+        const bool col_ok = gcol < N && lchk * 8 < ecw;        // N % 8 == 0: a chunk is inside or outside
         static_for<8>([&](auto MI_) __attribute__((always_inline)) {
             constexpr int mi = MI_;
             unsigned char* sb = stage + (mi & 1) * 4096;
@@ -325,11 +334,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     const int row = lrow + 4 * i;
                     *reinterpret_cast<Tx8*>(sb + row * 256 + ((lchk ^ row) << 4)) = rpre[mi & 1][i];
                 }
-                if (mi + 2 < 8) load_resid(em0, en0, mi + 2);
+                if (mi + 2 < 8) load_resid(em0, en0, ecw, mi + 2);
             }
             const float as = SCALED ? a_scale[min(mrow0 + fr, M - 1)] : 1.f;
             static_for<8>([&](auto NI_) __attribute__((always_inline)) {
                 constexpr int ni = NI_;
+                if constexpr (ni >= NT) return;
                 const int n = nb + ni * 16;
                 unsigned char* sp = sb + fr * 256 + ((((ni * 2) + (fq >> 1)) ^ fr) << 4) + (fq & 1) * 8;
                 const f32x4 av = acc_read<(mi * 8 + ni) * 4>();
@@ -372,6 +382,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     bool relaxed = false;
     for (;;) {
         const int em0 = m0, en0 = n0;
+        constexpr int ecw = CW;
         phase(ic<0>{}, ic<0>{}, 0, ic<0>{}, ic<1>{}, relaxed);
         phase(ic<0>{}, ic<1>{}, 0, ic<1>{}, ic<1>{}, relaxed);
         int t = 1;
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         __builtin_amdgcn_s_barrier();
         if (EPI == 3 || EPI == 4) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) load_resid(em0, en0, mi);
+            for (int mi = 0; mi < 2; ++mi) load_resid(em0, en0, ecw, mi);
         }
         fence();
         vb += gridDim.x;
@@ -410,13 +421,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         }
         fence();
         asm volatile("s_nop 15\ns_nop 15" ::: "memory");        // the last MFMAs retire before their tiles are read
-        epilogue(em0, en0);
+        epilogue(em0, en0, ecw);
         if (!more) break;
         // the operand pointers are recomputed rather than kept across the epilogue (32 VGPRs it needs itself)
         asm volatile("" : "+s"(vb));
         setup(vb);
         // a ragged tile skips stores, so the relaxed count would not cover the loads: drain instead
-        if (em0 + BM > M || en0 + BN > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (em0 + BM > M || en0 + 2 * CW > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         relaxed = true;
     }
 }
@@ -434,16 +445,16 @@ inline int persistent_grid() {
     return n;
 }
 
-template <typename T, int EPI, int AMODE, typename TO = T>
+template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8>
 int launch_w4(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
               void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
               const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
               const float* w_scale = nullptr) {
     // lane offsets inside a tile are 32-bit: 255 rows x the row stride in bytes has to fit
     if (lda >= (int64_t(1) << 22) || ldw >= (int64_t(1) << 22)) return (int)hipErrorInvalidValue;
-    const int ntm = (M + BM - 1) / BM, ntn = (N + BN - 1) / BN;
+    const int ntm = (M + BM - 1) / BM, ntn = (N + 32 * NT - 1) / (32 * NT);
     constexpr int smem = 2 * BUF_BYTES + 4 * 8192;        // operand buffers + the epilogue's row stage
-    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE>;
+    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     kern<<<dim3((unsigned)min(ntm * ntn, persistent_grid())), dim3(256), smem, st>>>((const T*)a, lda, a2_delta, k1, (const T*)w, ldw,

@@ -29,9 +29,11 @@ extern "C" int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, c
                       (epilogue < 3 || (((uintptr_t)resid & 15) == 0 && ldr % 8 == 0));
     switch (epilogue) {
         case 0:
+            if (wide && N <= 128) return launch_w4<f16, 0, 0, f16, 4>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
             return wide ? launch_w4<f16, 0, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st)
                         : launch<f16, 0, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
         case 4:
+            if (wide && N <= 128) return launch_w4<f16, 4, 0, f16, 4>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
             return wide ? launch_w4<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st)
                         : launch<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
         default: return (int)hipErrorInvalidValue;      // the VAE uses bias-only and bias+residual
@@ -46,8 +48,14 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
     // centre taps are packed t << 22 | h << 11 | w in gemm_w4.h, in tap coordinates (strided: twice the output's)
     FP_REQUIRE((cg.To << cg.dt) < 1024 && (cg.Ho << cg.dh) < 2048 && (cg.Wo << cg.dw) < 2048);
     const int M = (int)M64, N = Cout, K = 27 * cg.Cin;
-    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
+    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + 31) / 32) < (1ll << 31));
     const bool wide = ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
+    // Cout <= 128 / <= 32 (the last up block and conv_out): the narrow tiles of gemm_w4.h
+    if (wide && N <= 32 && !resid)
+        return launch_w4<f16, 0, 1, f16, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
+    if (wide && N <= 128)
+        return resid ? launch_w4<f16, 4, 1, f16, 4>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st)
+                     : launch_w4<f16, 0, 1, f16, 4>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
     if (resid)
         return wide ? launch_w4<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st)
                     : launch<f16, 4, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st);
