@@ -22,8 +22,15 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
     // contract asks for go to the 8-wave kernel
     const bool wide = ((uintptr_t)c & 15) == 0 && ldc % 8 == 0 && (epilogue < 3 || (((uintptr_t)resid & 15) == 0 && ldr % 8 == 0));
     const bool w4 = (g_variant & 1) && wide;
+    // Fewer 256 x 256 tiles than half the CUs (the per-rank row counts of 8-way sequence parallelism, the text
+    // stream): 256 x 128 tiles double the number of busy CUs at ~0.6 of the time per tile
+    const bool narrow = w4 && N > 128 &&
+                        (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) <= persistent_grid() / 2;
 #define FP_CASE(E)                                                                                                  \
     case E:                                                                                                         \
+        if (narrow)                                                                                                 \
+            return launch_w4<bf16, E, 0, bf16, 4>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from,  \
+                                                  resid, ldr, gate, cg, st);                                        \
         return w4 ? launch_w4<bf16, E, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from,    \
                                                  resid, ldr, gate, cg, st)                                          \
                          : launch<bf16, E, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, \
