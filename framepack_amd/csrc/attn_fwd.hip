@@ -746,10 +746,6 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
         }
         if (t < nt) step(t, ic<0>{});
     }
-#ifdef FP_W64_DEBUG
-    asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory");
-    const float dbg_o_before0 = agpr_read<0>(), dbg_o_before1 = agpr_read<16>();
-#endif
     // ---- the last tile's P.V
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -789,20 +785,6 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
     static_for<2>([&](auto rb) __attribute__((always_inline)) {
         const float inv = 1.f / l_tot[rb];
         const int qrow_real = q0 + wave * 64 + rb * 32 + r;
-#ifdef FP_W64_DEBUG
-        if (qrow_real < seg_hi && hh == 0) {
-            float* dbg = reinterpret_cast<float*>(O + (int64_t)qrow_real * o_rs + head * HD);
-            dbg[0] = l_tot[rb];
-            dbg[1] = m_run[rb];
-            dbg[2] = l_run[rb];
-            dbg[3] = (float)pf[rb][0][0];
-            dbg[4] = (float)pf[rb][0][1];
-            dbg[5] = agpr_read<(0 * 2 + rb) * 16 + 0>();
-            dbg[6] = rb == 0 ? dbg_o_before0 : dbg_o_before1;
-            dbg[7] = (float)pf[rb][1][0];
-        }
-        return;
-#endif
         if (qrow_real < seg_hi) {
             bf16* op = O + (int64_t)qrow_real * o_rs + head * HD + 4 * hh;
             static_for<4>([&](auto d) __attribute__((always_inline)) {
