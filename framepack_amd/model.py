@@ -635,6 +635,25 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         if hidden_states.dtype != BF16 or self.dtype != BF16:
             raise TypeError("the gfx950 kernels compute in bf16: load the model and pass hidden_states as torch.bfloat16")
         _lib.load()
+        if batch_size > 1:
+            # ref :932-941 packs a batch with cu_seqlens (segments [image + valid text | padded text] per sample) and
+            # needs a varlen kernel it may not have ("No Attn Installed!").  The rows it returns - the image tokens -
+            # attend to their own sample's image and valid text tokens only, so running the samples one after the
+            # other through the single-sample path returns exactly the same values, at full kernel efficiency
+            # (every sample already fills the chip).  TeaCache keeps ONE state for the batch in the reference.
+            if self.enable_teacache:
+                raise NotImplementedError("TeaCache with batch size > 1 is not supported: run the samples separately")
+
+            def cut(x, b):
+                return None if x is None else x[b:b + 1]
+            with torch.no_grad():
+                outs = [self._forward(*(cut(x, b) for x in (
+                    hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, pooled_projections,
+                    guidance, latent_indices, clean_latents, clean_latent_indices, clean_latents_2x,
+                    clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices, image_embeddings)), False)[0]
+                    for b in range(batch_size)]
+            out = torch.cat(outs, dim=0)
+            return Transformer2DModelOutput(sample=out) if return_dict else (out,)
         with torch.no_grad():
             return self._forward(hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
                                  pooled_projections, guidance, latent_indices, clean_latents, clean_latent_indices,
@@ -666,10 +685,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             ctx = torch.cat([extra, ctx], dim=1)                     # image tokens before text (ref :922-923)
             mask = torch.cat([torch.ones((B, extra.shape[1]), dtype=mask.dtype, device=mask.device), mask], dim=1)
 
-        if B != 1:
-            # Parity target = the reference's SDPA-only configuration, which has no varlen path for B > 1
-            # (ref :106-109).  The K1 kernel takes cu_seqlens (packing.get_cu_seqlens), the host loop does not yet.
-            raise NotImplementedError("No Attn Installed!")
+        assert B == 1          # forward() feeds a batch one sample at a time
         text_len = int(mask.sum().item())                           # ref :930 (one host sync per step)
         ctx = ctx[:, :text_len]
 

@@ -130,6 +130,29 @@ def test_teacache_schedule_matches_oracle(tiny):
     assert tc.hits > 0 and tc.misses > 0
 
 
+def test_batch_of_two_equals_the_samples_run_alone(tiny):
+    """ref :932-941 packs a batch with cu_seqlens (two segments per sample) so that a sample's image tokens see only
+    its own image and valid text tokens: the returned rows equal the single-sample results.  Two samples with
+    different text lengths, timesteps and latents; each against its own single-sample forward and the oracle."""
+    m, P32 = tiny
+    cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
+    a = synthetic.make_inputs(dtype=BF, seed=11, frames_latent=2, height=128, width=192, n_text=37, sigma=0.8)
+    b = synthetic.make_inputs(dtype=BF, seed=12, frames_latent=2, height=128, width=192, n_text=5, sigma=0.3)
+    both = {k: (torch.cat([a[k], b[k]], dim=0) if torch.is_tensor(a[k]) else a[k]) for k in a}
+    got = m(return_dict=False, **to_dev(both))[0]
+    assert got.shape[0] == 2
+    for i, kw in enumerate((a, b)):
+        alone = m(return_dict=False, **to_dev(kw))[0]
+        assert torch.equal(got[i:i + 1], alone)
+        assert rel_l2(got[i:i + 1], O.dit_forward(P32, cfg, **to_f32(kw))) < TOL
+    m.initialize_teacache(enable_teacache=True, num_steps=4)
+    try:
+        with pytest.raises(NotImplementedError):
+            m(return_dict=False, **to_dev(both))
+    finally:
+        m.initialize_teacache(enable_teacache=False)
+
+
 def test_fp8_weights_follow_reference_w8a16_semantics(tiny):
     """ref utils/fp8_optimization_utils.py: E4M3 weights + per-tensor scale, dequantise then bf16 GEMM."""
     from oracle import fp8_oracle as F8
