@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, teacache, ret):
+def _worker(rank, world, port, case, teacache, fp8_attention, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,6 +29,8 @@ def _worker(rank, world, port, case, teacache, ret):
         m = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_TINY).to(bf)
         synthetic.init_synthetic_(dict(m.state_dict()), seed=0)
         m = m.to(dev).eval()
+        if fp8_attention:
+            m.enable_fp8_attention()       # per-head scales over all rows: the same on one GPU and on a head group
         kw = synthetic.make_inputs(dtype=bf, **case)
         kw = {k: (v.to(dev) if torch.is_tensor(v) and v.dtype in (bf, torch.bool) else v) for k, v in kw.items()}
         sigmas = [1.0, 0.97, 0.9, 0.5] if teacache else [kw["timestep"].item() / 1000.0]
@@ -56,11 +58,12 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("case,teacache", [("config1", False), ("odd_text", False), ("config1", True)])
-def test_sequence_parallel_forward_equals_single_gpu(case, teacache):
+@pytest.mark.parametrize("case,teacache,fp8_attention", [("config1", False, False), ("odd_text", False, False),
+                                                         ("config1", True, False), ("config1", False, True)])
+def test_sequence_parallel_forward_equals_single_gpu(case, teacache, fp8_attention):
     world = 2
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), CASES[case], teacache, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), CASES[case], teacache, fp8_attention, ret), nprocs=world, join=True)
     assert len(ret) == world
     for err, same_counts in ret.values():
         # same kernels on the same values; only the order of the keys inside the attention (and the tile split of
