@@ -24,6 +24,11 @@
 //   * K and V tiles are 8 KiB each: half the LDS and global traffic.
 #include "fp_common.h"
 
+// attn_fwd.hip: merge of the split tail items (same partial layout: O[256][128] unnormalised, m[256], l[256], fp32)
+int fpi_attn_cu_count();
+int fpi_attn_combine(const float* ws, void* o, int64_t o_rs, int total, int heads, int nqb, int nwg_full, int split,
+                     int ntail, hipStream_t st);
+
 namespace {
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -31,6 +36,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int KVBLK = 64, HD = 128, QBLK = 256;
 constexpr int TILE_BYTES = KVBLK * HD;          // 8 KiB: one K or V tile in e4m3
+constexpr int WS_FLOATS = 256 * HD + 2 * 256;   // one partial sweep, as in attn_fwd.hip
 constexpr float FP8_MAX = 448.f;
 
 __host__ __device__ __forceinline__ int slot_key(int p) {
@@ -195,7 +201,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
                                                           const unsigned char* __restrict__ VT8,
                                                           const float* __restrict__ scales, bf16* __restrict__ O,
                                                           int64_t o_rs, int S, int heads, int nqb, int ntiles,
-                                                          float scale_log2e) {
+                                                          float scale_log2e, int nwg_full, int split,
+                                                          float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* kbuf = smem;                       // [2][8 KiB]
     unsigned char* vbuf = smem + 2 * TILE_BYTES;      // [2][8 KiB]
@@ -204,11 +211,30 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     const int grp = wave >> 2;
     const int r = lane & 31, hh = lane >> 5;
 
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    // items [0, nwg_full) are whole sweeps; the items of the last, partial round are cut into `split` KV ranges that
+    // write partial (O, m, l) for the merge kernel of attn_fwd.hip (same scheme as the bf16 kernel)
+    int w, part = 0, nparts = 1;
+    if ((int)blockIdx.x < nwg_full) {
+        w = xcd_remap(blockIdx.x, nwg_full);
+    } else {
+        const int si = blockIdx.x - nwg_full;
+        w = nwg_full + si / split;
+        part = si % split;
+        nparts = split;
+    }
     const int qb = w % nqb, head = w / nqb;
     const int q0 = qb * QBLK;
     const int C = heads * HD;
-    const int nt = ntiles;
+    const int t0 = (int)((int64_t)ntiles * part / nparts);           // this block's KV tiles: [t0, t0 + nt)
+    const int nt = (int)((int64_t)ntiles * (part + 1) / nparts) - t0;
+    float* wsp = ws + (int64_t)((w - nwg_full) * split + part) * WS_FLOATS;
+    if (nt == 0) {                                                   // (uniform) more parts than tiles: a neutral partial
+        for (int i = tid; i < 256; i += 512) {
+            wsp[256 * HD + i] = -INFINITY;
+            wsp[256 * HD + 256 + i] = 0.f;
+        }
+        return;
+    }
     const float c_log2 = scale_log2e * scales[head] * scales[heads + head];      // softmax scale x sq x sk
 
     // Q fragments: d = 64 ks + 32 hh .. + 32 of query row r
@@ -229,12 +255,12 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     int kt = 0, vt = 0;                                // next tile to load
     i32x4 kreg, vreg;
     auto load_k = [&]() {
-        const int row = min(min(kt, nt - 1) * KVBLK + skey, S - 1);
+        const int row = min((t0 + min(kt, nt - 1)) * KVBLK + skey, S - 1);
         kreg = *reinterpret_cast<const i32x4*>(kp_g + (int64_t)row * C);
         ++kt;
     };
     auto load_v = [&]() {
-        vreg = *reinterpret_cast<const i32x4*>(vp_g + (int64_t)min(vt, nt - 1) * TILE_BYTES);
+        vreg = *reinterpret_cast<const i32x4*>(vp_g + (int64_t)(t0 + min(vt, nt - 1)) * TILE_BYTES);
         ++vt;
     };
     auto write_k = [&](int buf) { *reinterpret_cast<i32x4*>(kbuf + buf * TILE_BYTES + k_dst) = kreg; };
@@ -281,8 +307,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
         // ================= vector segment: online softmax of S(t) -> P(t) in e4m3
         load_k();                               // K(t+2)  (clamped repeats past the end)
         load_v();                               // V(t+1)
-        if (t == nt - 1 && (S & (KVBLK - 1))) {
-            const int valid = S - t * KVBLK;
+        if (t0 + t == ntiles - 1 && (S & (KVBLK - 1))) {
+            const int valid = S - (t0 + t) * KVBLK;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -365,7 +391,28 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
 
-    const float inv = 1.f / (l_run + other_half(l_run));
+    const float l_tot = l_run + other_half(l_run);
+    if (nparts > 1) {                           // partial sweep: unnormalised O (fp32, v scales applied), max and sum
+        const int row = wave * 32 + r;
+        float* op = wsp + row * HD + 4 * hh;
+        const float* sv = scales + 2 * heads + head * HD + 4 * hh;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sv + d * 32 + g * 8);
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o_acc[d][4 * g + j] * s4[j];
+                *reinterpret_cast<f32x4*>(op + d * 32 + g * 8) = v;
+            }
+        if (hh == 0) {
+            wsp[256 * HD + row] = m_run;
+            wsp[256 * HD + 256 + row] = l_tot;
+        }
+        return;
+    }
+    const float inv = 1.f / l_tot;
     const int qrow = q0 + wave * 32 + r;
     if (qrow < S) {
         bf16* op = O + (int64_t)qrow * o_rs + head * HD + 4 * hh;
@@ -393,7 +440,7 @@ extern "C" int64_t fp_attn_fp8_workspace_bytes(int total_tokens, int heads) {
     const int64_t C = (int64_t)heads * HD, nt = (total_tokens + KVBLK - 1) / KVBLK;
     const int64_t nblk = (total_tokens + AMAX_ROWS - 1) / AMAX_ROWS;
     return 2 * align256((int64_t)total_tokens * C) + align256(heads * nt * TILE_BYTES) + align256((2 * heads + C) * 4) +
-           align256(3 * C * 4) + align256(nblk * 3 * C * 4);
+           align256(3 * C * 4) + align256(nblk * 3 * C * 4) + align256((int64_t)fpi_attn_cu_count() * WS_FLOATS * 4);
 }
 
 extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
@@ -423,6 +470,8 @@ extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void
     p += align256(3 * C * 4);
     float* partial = (float*)p;
     const int nblk = (S + AMAX_ROWS - 1) / AMAX_ROWS;
+    p += align256((int64_t)nblk * 3 * C * 4);
+    float* tail_ws = (float*)p;
     absmax_kernel<<<dim3((unsigned)nblk, (unsigned)((3 * C / 8 + 255) / 256)), dim3(256), 0, st>>>(
         (const bf16*)q, (const bf16*)k, (const bf16*)v, q_row_stride, k_row_stride, v_row_stride, S, C, partial);
     FP_CHECK_LAUNCH();
@@ -437,10 +486,23 @@ extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void
                                                                              scales, vt8);
     FP_CHECK_LAUNCH();
     const int nqb = (S + QBLK - 1) / QBLK;
-    FP_REQUIRE((int64_t)nqb * heads < (1ll << 31));
+    const int64_t nwg = (int64_t)nqb * heads;
+    FP_REQUIRE(nwg < (1ll << 31));
+    // one workgroup per CU is resident: when the last round is at most half full its items are cut into KV ranges
+    const int ncu = fpi_attn_cu_count();
+    int nwg_full = (int)nwg, split = 1;
+    const int tail = (int)(nwg % ncu);
+    if (nwg > ncu && tail > 0 && tail <= ncu / 2) {
+        split = ncu / tail < 8 ? ncu / tail : 8;
+        nwg_full = (int)nwg - tail;
+    }
+    const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
     auto kern = attn_fp8_kernel<8>;
-    kern<<<dim3((unsigned)(nqb * heads)), dim3(512), 4 * TILE_BYTES, st>>>(q8, k8, vt8, scales, (bf16*)o, o_row_stride, S,
-                                                                         heads, nqb, nt, softmax_scale * 1.4426950408889634f);
+    kern<<<dim3((unsigned)grid), dim3(512), 4 * TILE_BYTES, st>>>(q8, k8, vt8, scales, (bf16*)o, o_row_stride, S, heads, nqb,
+                                                                nt, softmax_scale * 1.4426950408889634f, nwg_full, split,
+                                                                tail_ws);
     FP_CHECK_LAUNCH();
+    if (nwg_full < nwg)
+        return fpi_attn_combine(tail_ws, o, o_row_stride, S, heads, nqb, nwg_full, split, (int)(nwg - nwg_full), st);
     return 0;
 }

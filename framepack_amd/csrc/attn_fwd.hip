@@ -864,6 +864,16 @@ extern "C" int fp_debug_attn_variant(int v) {
     return old;
 }
 
+// Library-internal (attn_fp8.hip): the merge of split tail items and the CU count behind the split decision.
+__attribute__((visibility("hidden"))) int fpi_attn_cu_count() { return cu_count(); }
+__attribute__((visibility("hidden"))) int fpi_attn_combine(const float* ws, void* o, int64_t o_rs, int total, int heads,
+                                                           int nqb, int nwg_full, int split, int ntail, hipStream_t st) {
+    attn_combine_kernel<<<dim3((unsigned)(ntail * 16)), dim3(256), 0, st>>>(ws, (bf16*)o, o_rs, nullptr, total, heads, nqb,
+                                                                            nwg_full, split);
+    FP_CHECK_LAUNCH();
+    return 0;
+}
+
 // Bytes of device workspace with which fp_attn_fwd_bf16 can split the last round's work items (any shape).
 extern "C" int64_t fp_attn_workspace_bytes(void) { return (int64_t)cu_count() * WS_FLOATS * 4; }
 

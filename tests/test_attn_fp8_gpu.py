@@ -93,6 +93,21 @@ def test_fp8_attention_constant_values_strided_views_and_aliasing():
     assert torch.equal(again, want)                                                 # deterministic
 
 
+def test_fp8_attention_split_last_round_matches_unsplit_sweeps():
+    """261 work items on a 256-CU chip: the 5 items of the last round are swept as 8 KV ranges each and merged (the
+    bf16 kernel's scheme and merge kernel).  Sampled rows inside the split items (incl. the ragged last query block
+    and last KV tile) and inside unsplit ones, against fp64 attention of the same quantised operands."""
+    S, heads = 86 * 256 + 10, 3
+    q, k, v = rand_qkv(S, heads, seed=21)
+    got = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    assert torch.isfinite(got.float()).all()
+    dq, dk, dv = dequantised(q, k, v, heads)
+    for h, lo, hi in ((2, 82 * 256, 82 * 256 + 40), (2, S - 40, S), (2, 0, 40), (0, 21000, 21040), (1, 11000, 11040)):
+        sl = slice(h * 128, (h + 1) * 128)
+        p = torch.softmax(dq[lo:hi, sl].double() @ dk[:, sl].double().T / math.sqrt(128.0), dim=-1)
+        assert rel_l2(got[lo:hi, sl], p @ dv[:, sl].double()) < 3e-2, (h, lo)
+
+
 def test_fp8_attention_rejects_bad_arguments():
     q = torch.zeros(8, 128, dtype=BF, device=DEV)
     with pytest.raises(AssertionError):
