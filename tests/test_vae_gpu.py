@@ -59,6 +59,8 @@ def ref_conv(x_cl, w, b, up=(1, 1, 1), resid=None):
     (3, 5, 6, 64, 128, (2, 2, 2), True),          # temporal + spatial (first frame not doubled)
     (1, 4, 4, 64, 64, (2, 2, 2), False),          # one frame in: one frame out
     (5, 40, 40, 128, 128, (1, 1, 1), True),       # several M tiles
+    (5, 32, 48, 64, 128, (1, 1, 1), True),        # a frame = 6 whole tiles
+    (3, 16, 16, 64, 256, (2, 2, 2), False),       # whole tiles per frame, with upsampling
 ])
 def test_conv3d_causal(T, H, W, cin, cout, up, with_res):
     x = rand(T, H, W, cin, seed=1)
