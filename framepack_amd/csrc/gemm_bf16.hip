@@ -2,6 +2,7 @@
 #include "gemm_w4.h"
 
 static int g_variant = 1;      // 0: 8-wave ping-pong pipeline | 1: one wave per SIMD
+__attribute__((visibility("hidden"))) int fpi_gemm_variant() { return g_variant; }      // gemm_fp8.hip follows the same switch
 extern "C" int fp_debug_gemm_variant(int v) {
     const int old = g_variant;
     if (v >= 0) g_variant = v;

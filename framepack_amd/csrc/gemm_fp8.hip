@@ -11,7 +11,9 @@
 // Numerics: e4m3 has 3 mantissa bits, so a GEMM with quantised ACTIVATIONS differs from the bf16 one by about
 // 2-4 % relative L2: outside SURVEY.md 8(c)'s 1e-2 bar, which is why the model only takes this path when asked
 // to (HunyuanVideoTransformer3DModelPacked.enable_fp8_compute) and the headline bench stays bf16.
-#include "gemm_pipeline.h"
+#include "gemm_w4.h"
+
+int fpi_gemm_variant();      // gemm_bf16.hip: 0 = 8-wave pipeline, 1 = one wave per SIMD
 
 namespace {
 
@@ -100,8 +102,15 @@ extern "C" int fp_gemm_fp8_bf16(const void* a, int64_t lda, const void* a_scale,
     if (M == 0) return 0;
     const ConvGeom cg{};
     hipStream_t st = (hipStream_t)stream;
+    // the 4-wave kernel moves output (and residual) rows 16 B per lane; operands aligned only to the 8 B the
+    // contract asks for go to the 8-wave kernel
+    const bool wide = ((uintptr_t)c & 15) == 0 && ldc % 8 == 0 && (epilogue < 3 || (((uintptr_t)resid & 15) == 0 && ldr % 8 == 0));
+    const bool w4 = (fpi_gemm_variant() & 1) && wide;
 #define FP_CASE(E)                                                                                                 \
     case E:                                                                                                        \
+        if (w4)                                                                                                    \
+            return launch_w4<fp8e4, E, 0, bf16>(a, lda, 0, K, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid,     \
+                                                ldr, gate, cg, st, (const float*)a_scale, (const float*)w_scale);  \
         return launch<fp8e4, E, 0, bf16>(a, lda, 0, K, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, \
                                          cg, st, (const float*)a_scale, (const float*)w_scale)
     switch (epilogue) {

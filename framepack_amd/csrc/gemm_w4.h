@@ -50,6 +50,14 @@ __device__ __forceinline__ void mfma_acc(const i32x4& w, const i32x4& a) {
             asm volatile("v_mfma_f32_16x16x32_f16 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
     }
 }
+// a[IDX:IDX+3] (+)= w . a for e4m3 operands: ONE 16x16x128 MFMA (32 bytes per lane and operand) per tile and K tile
+template <int IDX, bool ZERO_C>
+__device__ __forceinline__ void mfma8_acc(const i32x8& w, const i32x8& a) {
+    if constexpr (ZERO_C)
+        asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%0:%1], %2, %3, 0" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
+    else
+        asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%0:%1], %2, %3, a[%0:%1]" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
+}
 template <int IDX> __device__ __forceinline__ f32x4 acc_read() {
     float r0, r1, r2, r3;
     asm volatile("v_accvgpr_read_b32 %0, a[%4]\nv_accvgpr_read_b32 %1, a[%5]\nv_accvgpr_read_b32 %2, a[%6]\n"
@@ -218,7 +226,24 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
 
     // W fragments of the current K tile: [ks][ni].  A fragments: a ring of 4 groups; group g of a phase =
     // (ks = g >> 2, mi = 4 p + (g & 3)).
-    frag_t wf[2][8], af[4];
+    frag_t wf[KS == 2 ? 2 : 1][8], af[4];
+    // fp8 (KS == 1): a tile's operand is the pair of 16-B reads side by side.  A fragments of BOTH phases' row halves
+    // (the held-back MFMAs of a phase still read the previous half's), W fragments of the K tile.
+    i32x8 a8[KS == 1 ? 2 : 1][4], w8[KS == 1 ? 8 : 1];
+    auto rd_a8 = [&](auto BUF, auto P, auto MI) __attribute__((always_inline)) {
+        const unsigned char* p = smem + BUF * OP_BYTES + (P * 64 + MI * 16) * 128;
+        a8[KS == 1 ? (int)P : 0][MI] = __builtin_shufflevector(*reinterpret_cast<const frag_t*>(p + a_rd[0]),
+                                                               *reinterpret_cast<const frag_t*>(p + a_rd[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    auto rd_w8 = [&](auto BUF, auto NI) __attribute__((always_inline)) {
+        const unsigned char* p = smem + BUF * OP_BYTES + (NI * 16) * 128;
+        w8[KS == 1 ? (int)NI : 0] = __builtin_shufflevector(*reinterpret_cast<const frag_t*>(p + w_rd[0]),
+                                                            *reinterpret_cast<const frag_t*>(p + w_rd[1]), 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    // MFMA (row tile MI of half P, column tile NI); ZC: the tile's only K step of this K tile is its first
+    auto mfma8 = [&](auto P, auto MI, auto NI, auto ZC) __attribute__((always_inline)) {
+        mfma8_acc<((P * 4 + MI) * 8 + NI) * 4, ZC>(w8[KS == 1 ? (int)NI : 0], a8[KS == 1 ? (int)P : 0][MI]);
+    };
 
     auto rd_a = [&](auto BUF, auto P, auto G) __attribute__((always_inline)) {
         af[G & 3] = *reinterpret_cast<const frag_t*>(smem + a_rd[G >> 2] + BUF * OP_BYTES + (P * 64 + (G & 3) * 16) * 128);
@@ -252,30 +277,68 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     // relaxed: the 32 output stores of the previous tile may still be in flight behind the loads this phase needs
     // (memory operations retire in order), so the count that guarantees the loads is 16 + 32.
-    auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed) __attribute__((always_inline)) {
+    // PZC (fp8 only): ZC of the PREVIOUS phase, whose held-back tiles this phase issues (in the 16-bit loop the
+    // held-back groups are second K steps and never start a tile)
+    auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed, auto PZC) __attribute__((always_inline)) {
         // younger than the unit a phase needs are always 8 + NT pieces (4 of A-h0, 4 of A-h1, NT of W)
         if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NT + 32) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NT) : "memory");
         __builtin_amdgcn_s_barrier();
         fence();
-        if constexpr (P == 0) static_for<8>([&](auto ni) __attribute__((always_inline)) { rd_w(BUF, ic<0>{}, ni); });
-        rd_a(BUF, P, ic<0>{});
-        rd_a(BUF, P, ic<1>{});
-        fence();
-        if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind
-            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}); });
-            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}); });
-        }
-        fence();
-        static_for<6>([&](auto g) __attribute__((always_inline)) {
-            static_for<8>([&](auto k) __attribute__((always_inline)) {
-                mfma1(P, g, k, ZC);
-                fence();
-                slot(BUF, P, t, g, k);
-                fence();
+        if constexpr (KS == 1) {
+            // fp8: 32 MFMAs of 32 cycles per phase, column tile n outermost (its W fragment arrives two tiles
+            // ahead, in the gaps), the half's four A fragments read up front; tiles n = 6, 7 are held back behind
+            // the next barrier like the 16-bit loop's last two groups.
+            if constexpr (P == 0) {
+                rd_w8(BUF, ic<0>{});
+                rd_w8(BUF, ic<1>{});
+            }
+            static_for<4>([&](auto mi) __attribute__((always_inline)) { rd_a8(BUF, P, mi); });
+            fence();
+            if constexpr (HAVE_PREV) {
+                static_for<2>([&](auto n) __attribute__((always_inline)) {
+                    static_for<4>([&](auto mi) __attribute__((always_inline)) { mfma8(ic<1 - P>{}, mi, ic<6 + n>{}, PZC); });
+                });
+            }
+            fence();
+            static_for<6>([&](auto n) __attribute__((always_inline)) {
+                static_for<4>([&](auto mi) __attribute__((always_inline)) {
+                    mfma8(P, mi, n, ZC);
+                    fence();
+                    if constexpr (P == 0) {
+                        if constexpr (mi == 0) rd_w8(BUF, ic<n + 2>{});
+                        if constexpr (mi == 2 && n < 4) issue_a1(1, n, t + 1);
+                    } else {
+                        if constexpr (mi == 0) {
+                            if constexpr (n < 4) issue_a1(0, n, t + 2);
+                            else issue_w1(n - 4, t + 2);
+                        }
+                        if constexpr (mi == 2) issue_w1(2 + n, t + 2);
+                    }
+                    fence();
+                });
             });
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            if constexpr (P == 0) static_for<8>([&](auto ni) __attribute__((always_inline)) { rd_w(BUF, ic<0>{}, ni); });
+            rd_a(BUF, P, ic<0>{});
+            rd_a(BUF, P, ic<1>{});
+            fence();
+            if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind
+                static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}); });
+                static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}); });
+            }
+            fence();
+            static_for<6>([&](auto g) __attribute__((always_inline)) {
+                static_for<8>([&](auto k) __attribute__((always_inline)) {
+                    mfma1(P, g, k, ZC);
+                    fence();
+                    slot(BUF, P, t, g, k);
+                    fence();
+                });
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
     };
 
     // ---- epilogue of the tile at (em0, en0): lane (fr,fq) holds row em0 + wr*128 + mi*16 + fr,
@@ -375,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         });
     };
 
-    static_assert(KS == 2, "the 4-wave main loop is written for the 16-bit MFMA 16x16x32");
+    static_assert(KS == 2 || (KS == 1 && NT == 8), "16-bit MFMA 16x16x32 (two K steps per tile) or fp8 16x16x128 (one)");
     int vb = blockIdx.x;
     setup(vb);
     prologue();
@@ -383,26 +446,36 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     for (;;) {
         const int em0 = m0, en0 = n0;
         constexpr int ecw = CW;
-        phase(ic<0>{}, ic<0>{}, 0, ic<0>{}, ic<1>{}, relaxed);
-        phase(ic<0>{}, ic<1>{}, 0, ic<1>{}, ic<1>{}, relaxed);
+        phase(ic<0>{}, ic<0>{}, 0, ic<0>{}, ic<1>{}, relaxed, ic<0>{});
+        phase(ic<0>{}, ic<1>{}, 0, ic<1>{}, ic<1>{}, relaxed, ic<1>{});
         int t = 1;
         if (nk > 1) {
-            phase(ic<1>{}, ic<0>{}, 1, ic<1>{}, ic<0>{}, relaxed);
-            phase(ic<1>{}, ic<1>{}, 1, ic<1>{}, ic<0>{}, false);
+            phase(ic<1>{}, ic<0>{}, 1, ic<1>{}, ic<0>{}, relaxed, ic<1>{});
+            phase(ic<1>{}, ic<1>{}, 1, ic<1>{}, ic<0>{}, false, ic<0>{});
             for (t = 2; t + 1 < nk; t += 2) {
-                phase(ic<0>{}, ic<0>{}, t, ic<1>{}, ic<0>{}, false);
-                phase(ic<0>{}, ic<1>{}, t, ic<1>{}, ic<0>{}, false);
-                phase(ic<1>{}, ic<0>{}, t + 1, ic<1>{}, ic<0>{}, false);
-                phase(ic<1>{}, ic<1>{}, t + 1, ic<1>{}, ic<0>{}, false);
+                phase(ic<0>{}, ic<0>{}, t, ic<1>{}, ic<0>{}, false, ic<0>{});
+                phase(ic<0>{}, ic<1>{}, t, ic<1>{}, ic<0>{}, false, ic<0>{});
+                phase(ic<1>{}, ic<0>{}, t + 1, ic<1>{}, ic<0>{}, false, ic<0>{});
+                phase(ic<1>{}, ic<1>{}, t + 1, ic<1>{}, ic<0>{}, false, ic<0>{});
             }
             if (t < nk) {
-                phase(ic<0>{}, ic<0>{}, t, ic<1>{}, ic<0>{}, false);
-                phase(ic<0>{}, ic<1>{}, t, ic<1>{}, ic<0>{}, false);
+                phase(ic<0>{}, ic<0>{}, t, ic<1>{}, ic<0>{}, false, ic<0>{});
+                phase(ic<0>{}, ic<1>{}, t, ic<1>{}, ic<0>{}, false, ic<0>{});
             }
         }
         fence();
-        static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}); });
-        static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}); });
+        if constexpr (KS == 1) {
+            auto tail = [&](auto PZC) __attribute__((always_inline)) {
+                static_for<2>([&](auto n) __attribute__((always_inline)) {
+                    static_for<4>([&](auto mi) __attribute__((always_inline)) { mfma8(ic<1>{}, mi, ic<6 + n>{}, PZC); });
+                });
+            };
+            if (nk == 1) tail(ic<1>{});          // the only K tile's held-back tiles start from C = 0
+            else tail(ic<0>{});
+        } else {
+            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}); });
+            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}); });
+        }
         fence();
         // every wave is done with the LDS (and the clamped tail loads have landed): the next tile's first loads
         // go out BEFORE this tile's epilogue, whose stores then drain under the next main loop

@@ -50,11 +50,16 @@ for M, N, K, epi, name in SHAPES:
     aq = torch.empty(M, K, dtype=ops.FP8, device=dev)
     asc = torch.empty(M, dtype=torch.float32, device=dev)
     t_q = timed(lambda: ops.quantize_rows_fp8(a, out=aq, scale=asc))
+    from framepack_amd import lib as fplib
+    fplib.load().fp_debug_gemm_variant(0)          # the first-generation 8-wave pipeline
+    t_8w = timed(lambda: ops.gemm_fp8(aq, asc, wq, wsc, b, out=out, epilogue=epi, **kw))
+    o8w = out.clone()
+    fplib.load().fp_debug_gemm_variant(1)
     t_8 = timed(lambda: ops.gemm_fp8(aq, asc, wq, wsc, b, out=out, epilogue=epi, **kw))
     o8 = out.clone()
     t_16 = timed(lambda: ops.gemm(a, w, b, out=out, epilogue=epi, **kw))
     fl = 2.0 * M * N * K
     d = ((o8.float() - out.float()).norm() / out.float().norm()).item()
     print(f"{name:30s} M={M:6d} N={N:6d} K={K:6d}  bf16 {t_16:7.3f} ms {fl / t_16 / 1e9:7.0f} TF/s | "
-          f"fp8 {t_8:7.3f} ms {fl / t_8 / 1e9:7.0f} TF/s | quantise {t_q:6.3f} ms "
+          f"fp8 {t_8:7.3f} ms {fl / t_8 / 1e9:7.0f} TF/s (8-wave kernel {t_8w:7.3f} ms, max diff {(o8.float() - o8w.float()).abs().max().item():.3g}) | quantise {t_q:6.3f} ms "
           f"{(M * K * 3) / t_q / 1e6:6.0f} GB/s | fp8 vs bf16 rel-L2 {d:.4f}", flush=True)
