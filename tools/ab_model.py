@@ -1,5 +1,5 @@
 """Same-process A/B of kernel generations inside the 13B forward (ms per forward, alternating).
-usage: ab_gemm_model.py [gemm|attn]"""
+usage: ab_model.py [gemm|attn] [fp8]      (fp8: the opt-in e4m3 mode, linears and attention)"""
 import os
 import sys
 import time
@@ -16,6 +16,9 @@ with torch.device(dev):
     model = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_13B).to(bf)
 synthetic.init_synthetic_(dict(model.state_dict()), seed=0, fast_device_rng=True)
 model.eval()
+if "fp8" in sys.argv[2:]:
+    model.enable_fp8_compute()
+    model.enable_fp8_attention()
 kw = synthetic.make_inputs(seed=31337, frames_latent=9, height=640, width=640, n_text=256, dtype=bf)
 kw = {k: (v.to(dev) if torch.is_tensor(v) and v.dtype in (bf, torch.bool) else v) for k, v in kw.items()}
 L = lib.load()
