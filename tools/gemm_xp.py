@@ -19,7 +19,8 @@ if os.environ.get("FP_GEMM_VARIANT"):
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(0)
 res = []
-for M, N, K, epi in ((8192, 8192, 8192, 0), (19385, 3072, 15360, 3), (19385, 9216, 3072, 0), (19385, 21504, 3072, 2)):
+for M, N, K, epi in ((8192, 8192, 8192, 0), (19385, 3072, 15360, 3), (19385, 9216, 3072, 0), (19385, 21504, 3072, 2),
+                     (18400, 3072, 12288, 3), (18400, 12288, 3072, 1), (18400, 3072, 3072, 3)):
     a = torch.randn(M, K, generator=g, device=dev).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g, device=dev) * K ** -0.5).to(torch.bfloat16)
     b = torch.randn(N, generator=g, device=dev).to(torch.bfloat16)
@@ -29,6 +30,8 @@ for M, N, K, epi in ((8192, 8192, 8192, 0), (19385, 3072, 15360, 3), (19385, 921
         kw = dict(resid=torch.randn(M, N, generator=g, device=dev).to(torch.bfloat16), gate=b)
     if epi == 2:
         kw = dict(gelu_from=9216)
+    if epi == 1:
+        kw = {}
     for _ in range(3):
         ops.gemm(a, w, b, out=out, epilogue=epi, **kw)
     torch.cuda.synchronize()
