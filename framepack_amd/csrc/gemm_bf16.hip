@@ -17,7 +17,8 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
     if (int rc = check_dense(a, lda, a2, k1, w, ldw, bias, c, ldc, M, N, K, epilogue, gelu_from, resid, ldr, gate, a2_delta))
         return rc;
     if (M == 0) return 0;
-    const ConvGeom cg{};
+    ConvGeom cg{};
+    cg.gm = (K >= 8192 || N >= 16384) ? 2 : 8;      // see ConvGeom::gm
     hipStream_t st = (hipStream_t)stream;
     // the 4-wave kernel moves output (and residual) rows 16 B per lane; operands aligned only to the 8 B the
     // contract asks for go to the 8-wave kernel

@@ -43,8 +43,12 @@ constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
 // st/sh/sw = 1: the input is nearest-upsampled x2 on that axis on the fly (decoder); dt/dh/dw = 1: the convolution
 // has stride 2 on that axis (encoder downsamplers).  hmax/wmax: upper clamp of the tap coordinate (replicate
 // padding) in the coordinate system the taps are applied in (upsampled input, or input).
+// gm (gemm_w4.h, any A mode; 0 = 8): the tile walk takes gm row tiles x all column tiles at a time, so the 32 CUs
+// of an XCD run gm A panels against 32 / gm W panels.  Measured at S = 19385 (tools/gemm_xp.py, one box): gm = 2
+// against 8 gives -3 % on the long-K and the widest GEMMs (out-projection, ff2, in-projection) and +2..3 % on the
+// K = 3072 ones of middling width (qkv, ff1).
 struct ConvGeom {
-    int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw, dt, dh, dw, hmax, wmax;
+    int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw, dt, dh, dw, hmax, wmax, gm;
 };
 
 // OCP e4m3 storage type of the fp8 path (K6): one byte per element, so a 128-B LDS row holds 128 K values.

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr unsigned SECOND = SCALED ? 16u : 64u;
     const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
     auto setup = [&](int vb) __attribute__((always_inline)) {
-        constexpr int GM = 8;
+        const int GM = cg.gm > 0 ? cg.gm : 8;      // row tiles per group of the walk (ConvGeom::gm)
         const int wid = xcd_remap(vb, ntiles);
         const int per_group = GM * ntn;
         const int group = wid / per_group, in_group = wid % per_group;
