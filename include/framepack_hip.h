@@ -163,7 +163,9 @@ int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int toke
 /* ---- diagnostics (no counterpart in the reference) --------------------------------------------------------
  * Select the kernel generation used by fp_gemm_bf16 / fp_attn_fwd_bf16 for same-process A/B measurements
  * (tools/ab_model.py): 0 = first generation (8 waves per workgroup), 1 = second (one wave per SIMD; default).
- * v < 0 only queries.  Returns the previous value.  Process-wide, not thread-safe. */
+ * v < 0 only queries.  Returns the previous value.  Process-wide, not thread-safe.
+ * fp_gemm_fp8_bf16 follows the GEMM switch too.  For the GEMM, v >> 4 (when non-zero) overrides the number of row
+ * tiles per group of the tile walk (tools/gemm_xp.py scans it: FP_GEMM_VARIANT = 1 + 16 * gm). */
 int fp_debug_gemm_variant(int v);
 int fp_debug_attn_variant(int v);
 
