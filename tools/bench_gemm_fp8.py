@@ -54,7 +54,7 @@ for M, N, K, epi, name in SHAPES:
     fplib.load().fp_debug_gemm_variant(0)          # the first-generation 8-wave pipeline
     t_8w = timed(lambda: ops.gemm_fp8(aq, asc, wq, wsc, b, out=out, epilogue=epi, **kw))
     o8w = out.clone()
-    fplib.load().fp_debug_gemm_variant(1)
+    fplib.load().fp_debug_gemm_variant(int(os.environ.get("FP_GEMM_VARIANT", "1")))
     t_8 = timed(lambda: ops.gemm_fp8(aq, asc, wq, wsc, b, out=out, epilogue=epi, **kw))
     o8 = out.clone()
     t_16 = timed(lambda: ops.gemm(a, w, b, out=out, epilogue=epi, **kw))
