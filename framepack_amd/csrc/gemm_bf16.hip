@@ -18,8 +18,8 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
         return rc;
     if (M == 0) return 0;
     ConvGeom cg{};
-    cg.gm = (K >= 8192 || N >= 16384) ? 2 : 8;      // see ConvGeom::gm
-    if (g_variant >> 4) cg.gm = g_variant >> 4;     // diagnostics: fp_debug_gemm_variant(1 | gm << 4)
+    cg.gm = K >= 8192 ? -3 : (N >= 16384 ? 2 : 8);      // see ConvGeom::gm
+    if (g_variant >> 4) cg.gm = (g_variant & 8) ? -(g_variant >> 4) : (g_variant >> 4);     // diagnostics: 1 | gm << 4 (| 8: column-major walk)
     hipStream_t st = (hipStream_t)stream;
     // the 4-wave kernel moves output (and residual) rows 16 B per lane; operands aligned only to the 8 B the
     // contract asks for go to the 8-wave kernel

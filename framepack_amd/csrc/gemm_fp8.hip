@@ -101,7 +101,7 @@ extern "C" int fp_gemm_fp8_bf16(const void* a, int64_t lda, const void* a_scale,
     FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
     if (M == 0) return 0;
     ConvGeom cg{};
-    cg.gm = (K >= 8192 || N >= 16384) ? 2 : 8;      // tile walk, as fp_gemm_bf16 (ConvGeom::gm)
+    cg.gm = K >= 8192 ? -3 : (N >= 16384 ? 2 : 8);      // tile walk, as fp_gemm_bf16 (ConvGeom::gm)
     if (fpi_gemm_variant() >> 4) cg.gm = fpi_gemm_variant() >> 4;
     hipStream_t st = (hipStream_t)stream;
     // the 4-wave kernel moves output (and residual) rows 16 B per lane; operands aligned only to the 8 B the

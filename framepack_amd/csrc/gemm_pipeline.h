@@ -43,10 +43,11 @@ constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
 // st/sh/sw = 1: the input is nearest-upsampled x2 on that axis on the fly (decoder); dt/dh/dw = 1: the convolution
 // has stride 2 on that axis (encoder downsamplers).  hmax/wmax: upper clamp of the tap coordinate (replicate
 // padding) in the coordinate system the taps are applied in (upsampled input, or input).
-// gm (gemm_w4.h, any A mode; 0 = 8): the tile walk takes gm row tiles x all column tiles at a time, so the 32 CUs
-// of an XCD run gm A panels against 32 / gm W panels.  Measured at S = 19385 (tools/gemm_xp.py, one box): gm = 2
-// against 8 gives -3 % on the long-K and the widest GEMMs (out-projection, ff2, in-projection) and +2..3 % on the
-// K = 3072 ones of middling width (qkv, ff1).
+// gm (gemm_w4.h, any A mode; 0 = 8): the tile walk takes gm row tiles x all column tiles at a time (gm < 0: -gm
+// column tiles x all row tiles), so the 32 CUs of an XCD run gm A panels against 32 / gm W panels.  Measured at
+// S = 19385 (tools/gemm_xp.py, FP_GEMM_VARIANT = 1 + 16 gm [+ 8 for column-major], one box per scan): against gm = 8
+// the long-K GEMMs (out-projection, ff2) gain 3-6 % with 3 column tiles x all rows, the widest (in-projection) 3-5 %
+// with gm = 2, and the K = 3072 ones of middling width (qkv, ff1) lose 2-3 % with anything but 8.
 struct ConvGeom {
     int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw, dt, dh, dw, hmax, wmax, gm;
 };

@@ -125,13 +125,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr unsigned SECOND = SCALED ? 16u : 64u;
     const unsigned off_k0 = (unsigned)(fr * 128 + (((SCALED ? 2 * fq : fq) ^ (fr >> 1)) << 4));
     auto setup = [&](int vb) __attribute__((always_inline)) {
-        const int GM = cg.gm > 0 ? cg.gm : 8;      // row tiles per group of the walk (ConvGeom::gm)
+        // ConvGeom::gm: gm > 0: gm row tiles x all column tiles per group; gm < 0: -gm column tiles x all row tiles
+        const int GM = cg.gm != 0 ? abs(cg.gm) : 8;
         const int wid = xcd_remap(vb, ntiles);
-        const int per_group = GM * ntn;
+        const int nmaj = cg.gm < 0 ? ntn : ntm, nmin = cg.gm < 0 ? ntm : ntn;
+        const int per_group = GM * nmin;
         const int group = wid / per_group, in_group = wid % per_group;
-        const int first_m = group * GM;
-        const int gsz = min(ntm - first_m, GM);
-        const int tm = first_m + in_group % gsz, tn = in_group / gsz;
+        const int first = group * GM;
+        const int gsz = min(nmaj - first, GM);
+        const int tmaj = first + in_group % gsz, tmin = in_group / gsz;
+        const int tm = cg.gm < 0 ? tmin : tmaj, tn = cg.gm < 0 ? tmaj : tmin;
         m0 = tm * BM;
         n0 = tn * (2 * CW);
 #pragma unroll
