@@ -6,6 +6,10 @@
 // off: the wave interleaves its own LDS reads and LDS-DMA issues between MFMAs and meets the other three waves
 // only twice per K tile (every 64 MFMAs = 1024 matrix-pipe cycles).
 //
+// Used by: fp_gemm_bf16 / fp_gemm_f16 / fp_conv3d_causal*_f16 (16-bit MFMA 16x16x32, two K steps per tile: described
+// below) and fp_gemm_fp8_bf16 (e4m3, ONE MFMA 16x16x128 per tile and K tile: the `KS == 1` branch of `phase`).
+// Template NT narrows the tile for narrow outputs (see the kernel's comment); ConvGeom::gm sets the tile walk.
+//
 // Same LDS image, swizzle, operand swap (token row on the lane) and epilogues as gemm_pipeline.h.
 //   * K tile = 64 (128 B per row), two buffers of 32 KiB per operand, staged as THREE units per tile: A-h0 / A-h1 (rows 0-63 /
 //     64-127 of each wave row) and W (whole).  A K tile is two phases: phase p multiplies A-h{p} (4 row tiles)
