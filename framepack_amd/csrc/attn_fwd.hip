@@ -15,6 +15,7 @@
 //     V image: [d/32][key][64 B]                                      -> conflict-free tr reads.
 //   * Tails: rows are clamped on load, scores of keys past the segment end are masked to -inf in the
 //     last tile only, query rows past the end are not stored.  Nothing is padded in memory.
+#include <mutex>
 #include <type_traits>
 #include "fp_common.h"
 
@@ -880,11 +881,11 @@ extern "C" int64_t fp_attn_workspace_bytes(void) { return (int64_t)cu_count() * 
 // q, k, v, o: bf16 [total_tokens, heads, 128] with arbitrary row strides (elements) and head stride 128.
 // cu_seqlens: device int32 [nseg+1] or NULL for a single segment [0, total_tokens).
 // o may alias q (each workgroup reads its own Q rows before it writes them).
-extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
-                                int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
-                                const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens, int heads,
-                                int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes,
-                                void* stream) {
+// workspace_required: a workspace too small for the split last round is an error instead of "run unsplit".
+static int attn_launch(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride, int64_t k_row_stride,
+                       int64_t v_row_stride, int64_t o_row_stride, const int* cu_seqlens, int nseg, int max_seqlen,
+                       int total_tokens, int heads, int head_dim, float softmax_scale, void* workspace,
+                       int64_t workspace_bytes, bool workspace_required, void* stream) {
     FP_REQUIRE(q && k && v && o && head_dim == HD && heads > 0 && total_tokens >= 0 && nseg >= 1);
     FP_REQUIRE(max_seqlen >= 0 && max_seqlen <= total_tokens);
     FP_REQUIRE(q_row_stride % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && o_row_stride % 4 == 0);
@@ -911,6 +912,8 @@ extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
         split = ncu / tail < 8 ? ncu / tail : 8;
         if ((int64_t)tail * split * WS_FLOATS * 4 <= workspace_bytes && ((uintptr_t)workspace & 15) == 0)
             nwg_full = (int)nwg - tail;
+        else if (workspace_required)
+            return (int)hipErrorInvalidValue;       // the fixed scratch cannot hold this device's last round
         else
             split = 1;
     }
@@ -938,6 +941,58 @@ extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
             (const float*)workspace, (bf16*)o, o_row_stride, cu_seqlens, total_tokens, heads, nqb, nwg_full, split);
     FP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
+                                int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                                const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens, int heads,
+                                int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+    return attn_launch(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, cu_seqlens, nseg, max_seqlen,
+                       total_tokens, heads, head_dim, softmax_scale, workspace, workspace_bytes, false, stream);
+}
+
+// ---- The entry point that allocates nothing (no counterpart in the reference; for callers that cannot allocate:
+// HIP-graph capture, serving loops).  Same call as fp_attn_fwd_bf16 with the split last round always on: the fp32
+// partials go to a fixed array in device memory that every GPU the library runs on holds until the process ends.
+// In host code `scratch` is only a stand-in for the symbol: its per-device address comes from hipGetSymbolAddress,
+// once per device, and only that address is handed to kernels.
+constexpr int SCRATCH_PARTIALS = 256;           // one partial per CU of an MI355X: 256 x 133 120 B = 32.5 MiB
+static __device__ __align__(256) float scratch[(size_t)SCRATCH_PARTIALS * WS_FLOATS];
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static float* g_scratch_ptr[SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+static int scratch_for_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= SCRATCH_MAX_DEVICES) return (int)hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));      // the CURRENT device's copy of the array
+        if (e != hipSuccess) return (int)e;
+        if (!p) return (int)hipErrorInvalidSymbol;
+        g_scratch_ptr[dev] = (float*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int64_t fp_attn_static_scratch_bytes(void) { return (int64_t)SCRATCH_PARTIALS * WS_FLOATS * 4; }
+
+extern "C" int fp_attn_fwd_bf16_static(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
+                                       int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                                       const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens, int heads,
+                                       int head_dim, float softmax_scale, void* stream) {
+    float* ptr = nullptr;
+    const int e = scratch_for_current_device(&ptr);
+    if (e) return e;
+    // every partial the kernels read is written by the same call first (attn_*_kernel stores O, m, l of each part
+    // before attn_combine_kernel runs), so nothing in the array has to start at zero
+    return attn_launch(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, cu_seqlens, nseg, max_seqlen,
+                       total_tokens, heads, head_dim, softmax_scale, ptr, fp_attn_static_scratch_bytes(), true, stream);
 }
 
 #ifdef FP_ATTN_DIAG

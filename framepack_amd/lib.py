@@ -19,6 +19,8 @@ SIGNATURES = {
     "fp_abi_version": [],
     "fp_attn_workspace_bytes": [],
     "fp_attn_fwd_bf16": [P, P, P, P, L, L, L, L, P, I, I, I, I, I, F, P, L, P],
+    "fp_attn_static_scratch_bytes": [],
+    "fp_attn_fwd_bf16_static": [P, P, P, P, L, L, L, L, P, I, I, I, I, I, F, P],
     "fp_attn_fp8_workspace_bytes": [I, I],
     "fp_attn_fwd_fp8": [P, P, P, P, L, L, L, L, I, I, I, F, P, L, P],
     "fp_qk_rmsnorm_rope_bf16": [P, P, L, I, I, I, P, P, P, P, P, I, F, P],

@@ -44,6 +44,20 @@ int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o,
                      int heads, int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes,
                      void* stream);
 
+/* K1 for callers that cannot allocate or carry a workspace (HIP-graph capture, serving loops, harnesses that forbid
+ * hipMalloc).  NO counterpart in the reference.  Same arguments, kernels and result as fp_attn_fwd_bf16 called with a
+ * full workspace, but the split last round's fp32 partials live in a fixed device array inside the library
+ * (fp_attn_static_scratch_bytes() = 256 partials = 32.5 MiB, held by every GPU the library runs on until the process
+ * ends; its per-device address is looked up once per device, at the first call with that device current).  The call
+ * allocates nothing.  Limit: a shape whose last round needs more than 256 partials (only possible on a device with
+ * more than 256 CUs) is rejected with hipErrorInvalidValue and nothing is launched.  All calls on one GPU share the
+ * array: calls that overlap on one GPU (two streams, two threads) race; stream-ordered calls do not. */
+int64_t fp_attn_static_scratch_bytes(void);
+int fp_attn_fwd_bf16_static(const void* q, const void* k, const void* v, void* o,
+                            int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                            const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens,
+                            int heads, int head_dim, float softmax_scale, void* stream);
+
 /* K1, fp8 variant (opt-in; the role of the reference's quantised SageAttention branch, hunyuan_video_packed.py:92-94):
  * the same attention for ONE segment [0, total_tokens) with Q, K, P and V in e4m3 on the fp8 MFMA.  The call
  * quantises q, k, v (bf16, same strides as above) into `workspace` first - one scale per head for q and for k, one
