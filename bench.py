@@ -205,7 +205,7 @@ def main():
     if args.fp8:
         traffic = None                                      # the PMC passes were made on the bf16 kernel
     roofline = {"kernel": "attn_fp8_kernel<8> + its quantisation kernels (K1 fp8 variant, MFMA 32x32x64 f8f6f4)" if args.fp8
-                else "attn_w64_kernel<8> (K1 flash attention, bf16 MFMA 32x32x16, one wave per SIMD)", "bound": "mfma",
+                else "attn_v3_kernel<8> (K1 flash attention, bf16 MFMA 32x32x16, one wave per SIMD, S^T - m accumulated in VGPRs)", "bound": "mfma",
                 "achieved": round(achieved / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC, profiles/r1_g_attn_hbm_traffic.json; algorithmic 476 MB)",

@@ -33,350 +33,12 @@ __device__ __forceinline__ unsigned v_lds_off(int key, int chunk) {
     return (unsigned)((chunk >> 2) * (KVBLK * 64) + key * 64 + ((chunk & 3) << 4));
 }
 
-// Schedule.  Each wave's tile step is split into a vector segment V_t (online softmax of S(t) -> P(t)) and a matrix
-// segment M_t (O += V(t)^T.P(t), then S(t+1) = K(t+1).Q^T), with a workgroup barrier after each.  Waves 4-7
-// run one barrier behind waves 0-3, and waves w and w+4 share a SIMD: while one wave of a SIMD is in its matrix
-// segment the other is in its vector segment, so the matrix pipe and the vector ALU overlap instead of both
-// waves doing MFMAs and then both doing exp2 (the lockstep the one-barrier-per-tile loop falls into).
-// K runs two tiles ahead of V in LDS (M_t needs K(t+1) and V(t)); the global loads for K(t+2) / V(t+1) are
-// issued at the start of V_t and written to LDS at the end of M_t.
 // value of x in lane (lane ^ 32), without LDS: v_permlane32_swap exchanges the upper half of its first operand
 // with the lower half of its second
 __device__ __forceinline__ float other_half(float x) {
     const unsigned u = __float_as_uint(x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
-}
-
-// Diagnostic build only (-DFP_ATTN_DIAG, see tools/attn_diag.py): s_memtime stamps around the segments of the
-// tile loop, summed per wave into fp_attn_dbg by workgroup 8.  No stamp executes in the shipped build.
-#ifdef FP_ATTN_DIAG
-__device__ unsigned long long fp_attn_dbg[8 * 8];
-__device__ __forceinline__ unsigned long long stamp() {
-    unsigned long long t;
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    __builtin_amdgcn_sched_barrier(0);
-    return t;
-}
-#define FP_STAMP(var) var = stamp()
-#define FP_DIAG(...) __VA_ARGS__
-#else
-#define FP_STAMP(var)
-#define FP_DIAG(...)
-#endif
-
-template <int THR_LOG2>
-__global__ __launch_bounds__(512, 2) void attn_fwd_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
-                                                             const bf16* __restrict__ V, bf16* __restrict__ O,
-                                                             int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
-                                                             const int* __restrict__ cu_seqlens, int nseg, int total,
-                                                             int heads, int nqb, float scale_log2e, int nwg_full,
-                                                             int split, float* __restrict__ ws) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* kbuf = smem;                 // [2][KBUF]
-    unsigned char* vbuf = smem + 2 * KBUF;      // [2][KBUF]
-
-    constexpr int QBLK = 256;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int r = lane & 31, hh = lane >> 5;
-
-    // Work items [0, nwg_full) are whole (head, q block) sweeps, dealt so that consecutive items of one XCD share
-    // a head (K/V through its L2).  The items of the last, partial round are each cut into `split` KV ranges
-    // (blocks >= nwg_full) that write partial (O, m, l) to `ws` for attn_combine_kernel: the chip stays full.
-    int w, part = 0, nparts = 1;
-    if ((int)blockIdx.x < nwg_full) {
-        w = xcd_remap(blockIdx.x, nwg_full);
-    } else {
-        const int si = blockIdx.x - nwg_full;
-        w = nwg_full + si / split;
-        part = si % split;
-        nparts = split;
-    }
-    const int qb = w % nqb;
-    const int head = (w / nqb) % heads;
-    const int seg = w / (nqb * heads);
-    int seg_lo = 0, seg_hi = total;
-    if (cu_seqlens) {
-        seg_lo = cu_seqlens[seg];
-        seg_hi = cu_seqlens[seg + 1];
-    }
-    const int q0 = seg_lo + qb * QBLK;
-    if (q0 >= seg_hi) return;                   // uniform for the workgroup
-    const int nkv = seg_hi - seg_lo;
-    const int nt_all = (nkv + KVBLK - 1) / KVBLK;
-    const int t0 = (int)((int64_t)nt_all * part / nparts);          // this block's KV tiles: [t0, t0 + nt)
-    const int nt = (int)((int64_t)nt_all * (part + 1) / nparts) - t0;
-    float* wsp = ws + (int64_t)((w - nwg_full) * split + part) * WS_FLOATS;
-    if (nt == 0) {                              // (uniform) more parts than tiles: a neutral partial
-        for (int i = tid; i < 256; i += 512) {
-            wsp[256 * HD + i] = -INFINITY;
-            wsp[256 * HD + 256 + i] = 0.f;
-        }
-        return;
-    }
-
-    const int qrow = min(q0 + wave * 32 + r, seg_hi - 1);
-    bf16x8 qf[8];
-    {
-        const bf16* qp = Q + (int64_t)qrow * q_rs + head * HD + hh * 8;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-    }
-
-    // staging: keys sk0 and sk0 + 32 of a tile, 16-B chunk sc.  Addresses are uniform base + 32-bit byte offset
-    // (the launcher checks that an operand spans < 4 GiB); the offsets advance by one tile per step and are
-    // clamped to the segment's last row, so no 64-bit multiply sits in the loop.
-    const int sk0 = tid >> 4, sc = tid & 15;
-    const unsigned k_step = (unsigned)(KVBLK * k_rs * 2), v_step = (unsigned)(KVBLK * v_rs * 2);
-    const unsigned col_b = (unsigned)((head * HD + sc * 8) * 2);
-    const unsigned k_max = (unsigned)((seg_hi - 1) * k_rs * 2) + col_b, v_max = (unsigned)((seg_hi - 1) * v_rs * 2) + col_b;
-    unsigned k_cur[2], v_cur[2];                // byte offsets of this thread's two rows in the NEXT tile to load
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        k_cur[i] = (unsigned)((seg_lo + t0 * KVBLK + sk0 + 32 * i) * k_rs * 2) + col_b;
-        v_cur[i] = (unsigned)((seg_lo + t0 * KVBLK + sk0 + 32 * i) * v_rs * 2) + col_b;
-    }
-    u32x4 kreg[2], vreg[2];
-    auto load_k = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            kreg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(K) + min(k_cur[i], k_max));
-            k_cur[i] += k_step;
-        }
-    };
-    auto load_v = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            vreg[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(V) + min(v_cur[i], v_max));
-            v_cur[i] += v_step;
-        }
-    };
-    auto write_k = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<u32x4*>(kbuf + buf * KBUF + k_lds_off(sk0 + 32 * i, sc)) = kreg[i];
-    };
-    auto write_v = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<u32x4*>(vbuf + buf * KBUF + v_lds_off(sk0 + 32 * i, sc)) = vreg[i];
-    };
-
-    const int i16 = lane & 15;
-    const unsigned v_lane_off = (unsigned)((4 * hh + (i16 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
-
-    f32x16 o_acc[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) o_acc[d][j] = 0.f;
-    f32x16 s_acc[2];
-    bf16x8 pf[4];
-    float m_run = -INFINITY, l_run = 0.f;
-
-    auto qk = [&](int buf) {                    // S^T(tile in kbuf[buf]) = K.Q^T
-        const unsigned char* kp = kbuf + buf * KBUF;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) s_acc[kb][j] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(kp + k_lds_off(kb * 32 + r, 2 * ks + hh));
-                s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], s_acc[kb], 0, 0, 0);
-            }
-        }
-    };
-
-    // ---- prologue: K(0), V(0), K(1) into LDS; S(0)
-    load_k();
-    load_v();
-    write_k(0);
-    write_v(0);
-    load_k();                                   // K(1) (a clamped repeat when nt == 1)
-    write_k(1);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    qk(0);
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-
-    FP_DIAG(unsigned long long T0, Ta, Tb, Tc, T1, T2, T3, T4, T5, aLd = 0, aMx = 0, aRs = 0, aV = 0, aB1 = 0, aM = 0, aW = 0, aB2 = 0;)
-    for (int t = 0; t < nt; ++t) {
-        // ================= vector segment V_t
-        FP_STAMP(T0);
-        // unconditional (tile index clamped): a load under a runtime condition makes the compiler merge old
-        // and new register values right behind the load, i.e. wait for it at once
-        load_k();                               // K(t+2)
-        load_v();                               // V(t+1)
-
-        if (t0 + t == nt_all - 1 && (nkv & (KVBLK - 1))) {
-            const int valid = nkv - (t0 + t) * KVBLK;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int key = kb * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    if (key >= valid) s_acc[kb][j] = -INFINITY;
-                }
-        }
-        FP_STAMP(Ta);
-        float mx = s_acc[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s_acc[kb][j]);
-        mx = fmaxf(mx, other_half(mx)) * scale_log2e;
-        FP_DIAG(asm volatile("" ::"v"(mx));)
-        FP_STAMP(Tb);
-        if (!__all(mx - m_run <= (float)THR_LOG2)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) o_acc[d][j] *= alpha;
-        }
-        FP_DIAG(asm volatile("" ::"v"(o_acc[0]), "v"(o_acc[3]));)
-        FP_STAMP(Tc);
-        float rs = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][j], scale_log2e, -m_run));
-                rs += p;
-                pf[kb * 2 + (j >> 3)][j & 7] = (bf16)p;
-            }
-        l_run += rs;
-
-        FP_DIAG(asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]), "v"(l_run));)
-        FP_STAMP(T1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        FP_STAMP(T2);
-
-        // ================= matrix segment M_t
-        // Eight groups of four MFMAs: O^T d-blocks 0..3 (V^T fragments: 8 transposed reads each), then
-        // S^T(t+1) as (key block, k-step quad) x 4 (K fragments: 4 ds_read_b128 each).  The LDS reads of
-        // group g+2 are issued before the MFMAs of group g (three fragment sets), so that only the first
-        // group's LDS latency is exposed; the scheduling barriers keep hipcc from undoing that order.
-        __builtin_amdgcn_s_setprio(1);          // the matrix segment's issue slots come first
-        {
-            const unsigned char* vp = vbuf + (t & 1) * KBUF + v_lane_off;
-            const unsigned char* kp = kbuf + ((t + 1) & 1) * KBUF;
-            // S^T(t+1) is computed after the last tile too (from a stale K buffer, result unused): keeping the
-            // segment branch-free lets the LDS-read counts of consecutive groups chain exactly.
-            bf16x8 fa[3][4];
-            auto rd_v = [&](bf16x8(&f)[4], int d) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    union {
-                        s16x4 h[2];
-                        bf16x8 v;
-                    } a;
-                    a.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vp + d * (KVBLK * 64) + (16 * s) * 64));
-                    a.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4*)(vp + d * (KVBLK * 64) + (16 * s + 8) * 64));
-                    f[s] = a.v;
-                }
-            };
-            auto rd_k = [&](bf16x8(&f)[4], int kb, int kq) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    f[i] = *reinterpret_cast<const bf16x8*>(kp + k_lds_off(kb * 32 + r, 2 * (4 * kq + i) + hh));
-            };
-            // group g: 0..3 = O^T d-block g ; 4..7 = S^T key block (g-4)>>1, k-step quad (g-4)&1
-            auto rd = [&](bf16x8(&f)[4], int g) {
-                if (g < 4) rd_v(f, g);
-                else rd_k(f, (g - 4) >> 1, (g - 4) & 1);
-            };
-            rd(fa[0], 0);
-            rd(fa[1], 1);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                if (g + 2 < 8) rd(fa[(g + 2) % 3], g + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (g < 4) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        o_acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g % 3][s], pf[s], o_acc[g], 0, 0, 0);
-                } else {
-                    const int kb = (g - 4) >> 1, kq = (g - 4) & 1;
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)       // the chain's first MFMA takes the constant 0 as C (no register clear)
-                        s_acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[g % 3][i], qf[4 * kq + i],
-                                                                            (kq == 0 && i == 0) ? zero : s_acc[kb], 0, 0, 0);
-                }
-                if (g == 2) {
-                    // the tiles loaded at the start of V_t go to the LDS buffers nobody reads in this segment
-                    if (t + 2 < nt) write_k(t & 1);
-                    if (t + 1 < nt) write_v((t + 1) & 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        FP_DIAG(asm volatile("" ::"v"(s_acc[0]), "v"(s_acc[1]), "v"(o_acc[0]), "v"(o_acc[3]));)
-        FP_STAMP(T3);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        FP_STAMP(T4);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        FP_STAMP(T5);
-        FP_DIAG(aV += T1 - Tc; aLd += Ta - T0; aMx += Tb - Ta; aRs += Tc - Tb; aB1 += T2 - T1; aM += T3 - T2;
-                aW += T4 - T3; aB2 += T5 - T4;)
-    }
-    FP_DIAG(if (blockIdx.x == 8 && lane == 0) {
-        unsigned long long* d = fp_attn_dbg + wave * 8;
-        d[0] = aV; d[1] = aB1; d[2] = aM; d[3] = aW; d[4] = aB2; d[5] = nt; d[6] = aLd; d[7] = (aMx << 32) | aRs;
-    })
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-
-    const float l_tot = l_run + other_half(l_run);
-    if (nparts > 1) {                           // partial sweep: unnormalised O (fp32), running max and sum
-        const int row = wave * 32 + r;
-        float* op = wsp + row * HD + 4 * hh;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = o_acc[d][4 * g + j];
-                *reinterpret_cast<f32x4*>(op + d * 32 + g * 8) = v;
-            }
-        if (hh == 0) {
-            wsp[256 * HD + row] = m_run;
-            wsp[256 * HD + 256 + row] = l_tot;
-        }
-        return;
-    }
-    const float inv = 1.f / l_tot;
-    const int qrow_real = q0 + wave * 32 + r;
-    if (qrow_real < seg_hi) {
-        bf16* op = O + (int64_t)qrow_real * o_rs + head * HD + 4 * hh;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 v;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (bf16)(o_acc[d][4 * g + j] * inv);
-                *reinterpret_cast<bf16x4*>(op + d * 32 + g * 8) = v;
-            }
-    }
 }
 
 // ======================================================================================================
@@ -801,6 +463,497 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
     });
 }
 
+// ======================================================================================================
+// Third-generation sweep (default).  The second generation's structure - one wave per SIMD, 64 query rows per wave,
+// O^T in a[0:127], K / V by LDS-DMA into rings of 16 KiB slots, P.V one tile behind the softmax - with the VECTOR
+// stream, the longer of the two, cut from ~6 to ~2.8 instructions per score (measured with builds that leave one stream
+// out, tools/attn_skip_probe.sh: every vector instruction of the tile loop costs its full issue time - the matrix pipe
+// is busy 2048 of the loop's cycles and the vector issue port nearly as long - and on a busy chip the clock falls as
+// the loop gets denser, so the lever is fewer instructions, not a tighter interleave):
+//   * Q is multiplied by softmax_scale * log2(e) once, when it is loaded (fp32 multiply, one more bf16 rounding of q),
+//     and lives in AGPRs a[128:191] as the MFMAs' B operand;
+//   * S^T accumulates straight into VGPRs, and the first MFMA of each chain takes C = -m (a 16-register block per
+//     row block that holds the row's running max, negated): the accumulator IS s * scale * log2e - m, so a score costs
+//     one v_exp_f32, one v_add_f32 (row sum) and half a v_cvt_pk_bf16_f32 - no AGPR read, no fma;
+//   * no row max in the common case: P = exp2(s - m) is computed with the running max as it stands, and the packed
+//     bf16 P dwords are max-reduced two at a time (v_pk_maximum3_f16 on their bit patterns: non-negative bf16 order as
+//     their bits do).  Only when some P exceeds 2^THR - the row's max has grown by more than THR - is the tile redone
+//     on a slow path: true row max, m += growth, O and l rescaled, the tile's and the next tile's accumulators shifted,
+//     P recomputed.  The first tile always takes it (m starts at 0);
+//   * every LDS fragment read is inline asm with a counted lgkmcnt in front of its first MFMA, and the first three V^T
+//     fragments of the NEXT tile are requested behind this tile's last MFMAs (V runs two tiles ahead in a 4-slot ring,
+//     so that tile's V is known to have landed one barrier earlier): no LDS latency is exposed behind the barrier;
+//   * exp2 items are dealt one per MFMA gap, their add / pack one gap later (no wait state behind a transcendental).
+//   iteration t:   MFMA stream   slots  0..31  O^T += V(t-1)^T . P(t-1)^T
+//                                slots 32..63  S^T(t+1) = K(t+1) . Q'^T - m      (into the VGPR set S(t) is not in)
+//                  other         slots  0..7   the 8 LDS-DMA pieces of K(t+3), V(t+2)
+//                                slots  8..63  64 exp2, 64 adds, 32 packs, 16 packed max3 (exp h behind MFMA 8 + 7h/8: the
+//                                              P^T fragment an item completes was consumed by slot 8 (h/16) + 7)
+//                                even slots    one fragment read (f + 3 while f is multiplied)
+// Timing-only builds (tools/attn_skip_probe.sh): -DFP_V3_SKIP=<mask> leaves one stream of the tile loop out (results are
+// then wrong): 1 exp2/pack/sum items, 2 LDS fragment reads, 4 LDS-DMA issues, 8 the per-tile barrier, 16 P.V MFMAs,
+// 32 Q.K MFMAs, 128 never take the slow path after the first tile (for builds whose scores are garbage).  The shipped
+// library is built without it.
+#ifndef FP_V3_SKIP
+#define FP_V3_SKIP 0
+#endif
+// -DFP_V3_DIAG (probe builds only): shader-clock and 100 MHz real-time stamps around the whole tile loop of the first
+// wave of workgroup 8 -> fp_attn_dbg = {cycles, real-time ticks, tiles, slow-path count}; read with fp_attn_dbg_read.
+// In the shipped build no stamp executes.  The stamps go straight to memory: nothing of them is carried in registers
+// across the loop (this kernel has none to spare).
+#ifdef FP_V3_DIAG
+__device__ unsigned long long fp_attn_dbg[8];
+#endif
+// s = A . Q'[QIDX] + c   (first MFMA of a chain; D and C are different VGPR blocks)
+template <int QIDX, int LGKM> __device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& a, const f32x16& c) {
+    asm volatile("s_waitcnt lgkmcnt(%5)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %4"
+                 : "=&v"(s) : "v"(a), "n"(QIDX), "n"(QIDX + 3), "v"(c), "n"(LGKM));
+}
+template <int QIDX, int LGKM> __device__ __forceinline__ void mfma_s_next(f32x16& s, const bf16x8& a) {
+    asm volatile("s_waitcnt lgkmcnt(%4)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0"
+                 : "+v"(s) : "v"(a), "n"(QIDX), "n"(QIDX + 3), "n"(LGKM));
+}
+template <int QIDX> __device__ __forceinline__ void mfma_s_first_nw(f32x16& s, const bf16x8& a, const f32x16& c) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %4" : "=&v"(s) : "v"(a), "n"(QIDX), "n"(QIDX + 3), "v"(c));
+}
+template <int QIDX> __device__ __forceinline__ void mfma_s_next_nw(f32x16& s, const bf16x8& a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(s) : "v"(a), "n"(QIDX), "n"(QIDX + 3));
+}
+// packed max of three dwords of two non-negative bf16 each, on their bit patterns read as f16 (same order; a pattern
+// that is a NaN as f16 - a bf16 above 2^120 - propagates, and compares above the threshold as an integer)
+__device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c) {
+    unsigned d;
+    asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+constexpr int v3_exp_lo(int m) { return m < 8 ? 0 : (8 * (m - 8) + 6) / 7; }       // exps h with 8 + 7h/8 == m:
+constexpr int v3_exp_hi(int m) { return m < 7 ? 0 : (8 * (m - 7) + 6) / 7; }       // [lo, hi)
+// LDS-DMA instruction k (0..7) of a tile goes behind MFMA slot k: the gaps before the exp2 items start
+#ifndef FP_V3_DMA_SLOTS
+#define FP_V3_DMA_SLOTS 0, 1, 2, 3, 4, 5, 6, 7
+#endif
+constexpr int v3_dma_of_slot(int m) {
+    constexpr int slots[8] = {FP_V3_DMA_SLOTS};
+    for (int k = 0; k < 8; ++k)
+        if (slots[k] == m) return k;
+    return -1;
+}
+// LDS read instructions still in flight behind fragment f when its first MFMA issues: fragments f+1 and f+2
+// (V^T fragments 0..15 take two reads, K fragments 16..31 one, 32..34 are the next tile's first V^T fragments)
+constexpr int v3_reads_of(int f) { return f < 16 ? 2 : (f < 32 ? 1 : 2); }
+constexpr int v3_lgkm(int f) { return v3_reads_of(f + 1) + v3_reads_of(f + 2); }
+
+template <int THR_LOG2>
+__global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
+                                                         const bf16* __restrict__ V, bf16* __restrict__ O,
+                                                         int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
+                                                         const int* __restrict__ cu_seqlens, int nseg, int total,
+                                                         int heads, int nqb, float scale_log2e, int nwg_full,
+                                                         int split, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // K ring [3][16 KiB] | V ring [4][16 KiB]
+    constexpr int VRING = 3 * KBUF;
+    constexpr int QBLK = 256;
+    constexpr int QA = 128;                     // Q' fragments: a[QA + (rb * 8 + ks) * 4 ..]
+    constexpr unsigned THR_BITS = (unsigned)(127 + THR_LOG2) << 7;      // bf16 bit pattern of 2^THR
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    asm volatile("" ::: "a0", "a255");          // the kernel descriptor must count the AGPRs the asm below names
+
+    int w, part = 0, nparts = 1;
+    if ((int)blockIdx.x < nwg_full) {
+        w = xcd_remap(blockIdx.x, nwg_full);
+    } else {
+        const int si = blockIdx.x - nwg_full;
+        w = nwg_full + si / split;
+        part = si % split;
+        nparts = split;
+    }
+    const int qb = w % nqb;
+    const int head = (w / nqb) % heads;
+    const int seg = w / (nqb * heads);
+    int seg_lo = 0, seg_hi = total;
+    if (cu_seqlens) {
+        seg_lo = cu_seqlens[seg];
+        seg_hi = cu_seqlens[seg + 1];
+    }
+    const int q0 = seg_lo + qb * QBLK;
+    if (q0 >= seg_hi) return;                   // uniform for the workgroup
+    const int nkv = seg_hi - seg_lo;
+    const int nt_all = (nkv + KVBLK - 1) / KVBLK;
+    const int t0 = (int)((int64_t)nt_all * part / nparts);
+    const int nt = (int)((int64_t)nt_all * (part + 1) / nparts) - t0;
+    float* wsp = ws + (int64_t)((w - nwg_full) * split + part) * WS_FLOATS;
+    if (nt == 0) {
+        for (int i = tid; i < 256; i += 256) {
+            wsp[256 * HD + i] = -INFINITY;
+            wsp[256 * HD + 256 + i] = 0.f;
+        }
+        return;
+    }
+
+    // ---- Q' = bf16(q * scale * log2e) -> AGPRs
+    static_for<2>([&](auto RB) __attribute__((always_inline)) {
+        const int qrow = min(q0 + wave * 64 + RB * 32 + r, seg_hi - 1);
+        const bf16* qp = Q + (int64_t)qrow * q_rs + head * HD + hh * 8;
+        static_for<8>([&](auto KS_) __attribute__((always_inline)) {
+            const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qp + KS_ * 16);
+            static_for<4>([&](auto I_) __attribute__((always_inline)) {
+                const unsigned pw = cvt_pk_bf16((float)qv[2 * I_] * scale_log2e, (float)qv[2 * I_ + 1] * scale_log2e);
+                agpr_write<QA + (RB * 8 + KS_) * 4 + I_>(__uint_as_float(pw));
+            });
+        });
+    });
+
+    // ---- LDS-DMA staging.  K: instruction i of this wave = keys wave*16 + 4 i + (0..3), lane = (key, 16-B position);
+    //      the lane fetches the chunk that belongs at its position under the image's XOR.  V: instruction i = d-block
+    //      `wave`, keys 16 i + (0..15), lane = (key, 16-B piece of the 64-B row).
+    // Source offset of piece i = min(lane row + tile + i * 4 rows, last row) + lane column.  The tile term is scalar; the
+    // lane terms are re-declared opaque at each use, else LICM keeps "row + i * pitch" and the XOR columns in a dozen
+    // registers this kernel does not have (it uses all 256 VGPRs + 256 AGPRs).
+    const unsigned k_step = (unsigned)(KVBLK * k_rs * 2), v_step = (unsigned)(KVBLK * v_rs * 2);
+    const unsigned k_rowmax = (unsigned)((seg_hi - 1) * k_rs * 2), v_rowmax = (unsigned)((seg_hi - 1) * v_rs * 2);
+    const unsigned k_i = (unsigned)(4 * k_rs * 2), v_i = (unsigned)(16 * v_rs * 2);
+    unsigned k_row0 = (unsigned)((wave * 16 + (lane >> 4)) * k_rs * 2);          // lane term of the K row
+    unsigned v_row0 = (unsigned)((lane >> 2) * v_rs * 2);                        // lane term of the V row
+    unsigned k_tile = (unsigned)((seg_lo + t0 * KVBLK) * k_rs * 2);              // next K tile to load (scalar)
+    unsigned v_tile = (unsigned)((seg_lo + t0 * KVBLK) * v_rs * 2);              // next V tile to load (scalar)
+    const unsigned v_col = (unsigned)((head * HD + wave * 32 + (lane & 3) * 8) * 2);
+    // K column of piece i: the chunk that belongs at this lane's LDS position under the image's XOR,
+    // ((lane & 15) ^ ((4 i + (lane >> 4)) & 15)) * 16 B = k_col0 ^ (i << 6)
+    unsigned k_col0 = (unsigned)(head * HD * 2) + (((lane & 15) ^ (lane >> 4)) << 4);
+    auto issue_k = [&](int i, int slot) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(k_row0), "+v"(k_col0));
+        const unsigned off = min(k_row0 + (k_tile + i * k_i), k_rowmax) + (k_col0 ^ (unsigned)(i << 6));
+        dma16(reinterpret_cast<const unsigned char*>(K) + off, smem + slot * KBUF + (wave * 16 + i * 4) * 256);
+    };
+    auto issue_v = [&](int i, int slot) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(v_row0));
+        const unsigned off = min(v_row0 + (v_tile + i * v_i), v_rowmax) + v_col;
+        dma16(reinterpret_cast<const unsigned char*>(V) + off, smem + VRING + slot * KBUF + wave * (KVBLK * 64) + i * 1024);
+    };
+
+    // ---- fragment read addresses
+    const int i16 = lane & 15;
+    const unsigned v_lane_off = (unsigned)(VRING + (4 * hh + (i16 >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (i16 & 3)) * 2);
+    // K fragment (kb, ks) of lane (r, hh): row kb*32 + r, chunk (2 ks + hh) ^ (r & 15) = (2 ks) ^ (hh ^ (r & 15)); with the
+    // lane's XOR term folded into the base, the chunk of k-step ks is base ^ (ks << 5)
+    const unsigned k_lane_base = (unsigned)(r * 256) + ((unsigned)(hh ^ (r & 15)) << 4);
+
+    // ---- state
+    f32x16 S[2][2][2];                           // [tile parity][rb][kb], key of element j = kb*32 + (j&3) + 8*(j>>2) + 4*hh
+    f32x16 negm[2];                              // -m_run[rb] in all 16 registers: the C operand of a chain's first MFMA
+    bf16x8 pf[2][4];                             // P(t-1)/P(t): [rb][k-step]
+    bf16x8 fr[4];                                // fragment ring (three fragments = 6 MFMAs ahead), carried across tiles
+    float l_run[2] = {0.f, 0.f};                 // the running max of a row block is -negm[rb][0]
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) negm[rb][j] = 0.f;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[rb][s4][e] = (bf16)0.f;
+    }
+    asm volatile(".set fp_i, 0\n.rept 128\nv_accvgpr_write_b32 a[fp_i], 0\n.set fp_i, fp_i + 1\n.endr" ::: "memory");
+
+    auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
+    // all fragment reads are asm: invisible to the compiler's lgkmcnt bookkeeping, their consumers wait explicitly
+    auto rd_k = [&](bf16x8& f, unsigned& kbase, auto KB, auto KS_) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(kbase));          // opaque: else the eight XORed addresses are kept in registers
+        const unsigned a = kbase ^ (unsigned)(KS_ << 5);
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a), "n"(KB * 8192));
+    };
+    auto rd_v = [&](bf16x8& f, unsigned vbase, auto D, auto S4) __attribute__((always_inline)) {
+        union {
+            u32x2 h[2];
+            bf16x8 v;
+        } a;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[0]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4) * 64));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[1]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4 + 8) * 64));
+        f = a.v;
+    };
+
+    // ---- prologue: K(0), K(1), V(0), K(2), V(1).  Tile j of K lives in ring slot j % 3, of V in j % 4.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(i, 0);
+    k_tile += k_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(i, 1);
+    k_tile += k_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_v(i, 0);
+    v_tile += v_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_k(i, 2);
+    k_tile += k_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_v(i, 1);
+    v_tile += v_step;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // K(0), K(1), V(0) landed
+    __builtin_amdgcn_s_barrier();
+    {   // S^T(0) = K(0) . Q'^T (m = 0) -> S[0]
+        unsigned kbase = k_lane_base;
+        static_for<8>([&](auto ks) __attribute__((always_inline)) {
+            static_for<2>([&](auto kb) __attribute__((always_inline)) {
+                bf16x8 f;
+                rd_k(f, kbase, kb, ks);
+                static_for<2>([&](auto rb) __attribute__((always_inline)) {
+                    if constexpr (ks == 0) mfma_s_first<QA + (rb * 8 + ks) * 4, 0>(S[0][rb][kb], f, negm[rb]);
+                    else mfma_s_next<QA + (rb * 8 + ks) * 4, 0>(S[0][rb][kb], f);
+                });
+            });
+        });
+    }
+    // the first tile's P.V multiplies P = 0 with V(0) (finite data; the product must not be NaN): its first fragments
+    rd_v(fr[0], v_lane_off, ic<0>{}, ic<0>{});
+    rd_v(fr[1], v_lane_off, ic<1>{}, ic<0>{});
+    rd_v(fr[2], v_lane_off, ic<2>{}, ic<0>{});
+
+    int kslot_rd = 1, kslot_wr = 0;              // K(t+1) is read, K(t+3) written: for t = 0
+    int vslot_rd = 0, vslot_nx = 0, vslot_wr = 2;   // V(t-1) (V(0) for t = 0) is read, V(t) prefetched, V(t+2) written
+    // One tile step.  PAR = t & 1: S(t) sits in S[PAR], S(t+1) is accumulated into S[1 - PAR].
+    auto step = [&](int t, auto PAR) __attribute__((always_inline)) {
+        constexpr int CUR = PAR, NXT = 1 - PAR;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // all but this wave's last 8 pieces: K(t+1), V(t) are in
+        if constexpr (!(FP_V3_SKIP & 8)) __builtin_amdgcn_s_barrier();
+        fence();
+        unsigned kbase = (unsigned)(kslot_rd * KBUF) + k_lane_base;
+        const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
+        const bool first = t == 0;
+        float ev[4], rs[2] = {0.f, 0.f};     // exp ring: at most four values wait for their add / pack
+        unsigned pm = 0;
+        // row-sum add of exp h and, with the second value of a pair, the pack into its P^T dword; every second pair
+        // folds its dword and the previous one into the running packed max
+        auto finish_exp = [&](auto H_) __attribute__((always_inline)) {
+            constexpr int h = H_, i = h >> 1, s4 = i >> 3, rb = (i >> 2) & 1, dw = i & 3;
+            rs[rb] += ev[h & 3];
+            asm volatile("" : "+v"(rs[rb]));
+            if constexpr (h & 1) {
+                union {
+                    unsigned u[4];
+                    bf16x8 v;
+                } pk;
+                pk.v = pf[rb][s4];
+                unsigned pw = cvt_pk_bf16(ev[(h - 1) & 3], ev[h & 3]);
+                asm volatile("" : "+v"(pw));
+                pk.u[dw] = pw;
+                pf[rb][s4] = pk.v;
+                if constexpr (i & 1) pm = pk_max3(pm, pk.u[dw - 1], pw);
+            }
+        };
+        if ((t0 + t == nt_all - 1) && (nkv & (KVBLK - 1))) {          // ragged last tile: keys past the end score -inf
+            // the lane's first invalid key offset, opaque and defined in here: hoisted out of the loop, the 32 compare
+            // masks would sit in 64 SGPRs for the whole sweep
+            int lim = nkv - (t0 + t) * KVBLK - 4 * hh;
+            asm volatile("s_nop 15\ns_nop 7" : "+v"(lim)::"memory");  // (and the last MFMAs of S(t) have retired)
+#pragma unroll
+            for (int rb2 = 0; rb2 < 2; ++rb2)
+#pragma unroll
+                for (int kb2 = 0; kb2 < 2; ++kb2)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (kb2 * 32 + (j & 3) + 8 * (j >> 2) >= lim) S[CUR][rb2][kb2][j] = -INFINITY;
+        }
+        fence();
+        static_for<64>([&](auto M_) __attribute__((always_inline)) {
+            constexpr int m = M_;
+            constexpr int f = m >> 1;                                 // fragment of this slot (0..15 V^T, 16..31 K)
+            // ---------------- the MFMA of this slot
+            if constexpr (m < 32) {
+                constexpr int s4 = m >> 3, d = (m >> 1) & 3, rb = m & 1;
+                if constexpr (FP_V3_SKIP & 16) asm volatile("" ::"v"(fr[f & 3]), "v"(pf[rb][s4]));
+                else if constexpr (rb == 0) mfma32_after<(d * 2 + rb) * 16, v3_lgkm(f)>(fr[f & 3], pf[rb][s4]);
+                else mfma32<(d * 2 + rb) * 16, false>(fr[f & 3], pf[rb][s4]);
+            } else {
+                constexpr int q = m - 32, ks = q >> 2, kb = (q >> 1) & 1, rb = q & 1;
+                if constexpr (FP_V3_SKIP & 32) asm volatile("" : "+v"(S[NXT][rb][kb]) : "v"(fr[f & 3]));
+                else if constexpr (rb == 0 && ks == 0) mfma_s_first<QA + (rb * 8 + ks) * 4, v3_lgkm(f)>(S[NXT][rb][kb], fr[f & 3], negm[rb]);
+                else if constexpr (rb == 0) mfma_s_next<QA + (rb * 8 + ks) * 4, v3_lgkm(f)>(S[NXT][rb][kb], fr[f & 3]);
+                else if constexpr (ks == 0) mfma_s_first_nw<QA + (rb * 8 + ks) * 4>(S[NXT][rb][kb], fr[f & 3], negm[rb]);
+                else mfma_s_next_nw<QA + (rb * 8 + ks) * 4>(S[NXT][rb][kb], fr[f & 3]);
+            }
+            fence();
+            // ---------------- LDS reads: fragment f+3 while fragment f is multiplied (one fragment per two slots);
+            // fragments 32..34 are the first three V^T fragments of the next tile's P.V
+            if constexpr ((m & 1) == 0 && !(FP_V3_SKIP & 2)) {
+                constexpr int f2 = f + 3;
+                if constexpr (f2 < 16) rd_v(fr[f2 & 3], vbase, ic<f2 & 3>{}, ic<(f2 >> 2)>{});
+                else if constexpr (f2 < 32) rd_k(fr[f2 & 3], kbase, ic<(f2 - 16) & 1>{}, ic<((f2 - 16) >> 1)>{});
+                else rd_v(fr[f2 & 3], (unsigned)(vslot_nx * KBUF) + v_lane_off, ic<(f2 - 32) & 3>{}, ic<0>{});
+            }
+            // ---------------- LDS-DMA: K(t+3) and V(t+2)
+            if constexpr (v3_dma_of_slot(m) >= 0 && !(FP_V3_SKIP & 4)) {
+                constexpr int i = v3_dma_of_slot(m);
+                if constexpr (i < 4) issue_k(i, kslot_wr);
+                else issue_v(i - 4, vslot_wr);
+            }
+            // ---------------- P(t) = exp2(S(t)): exp h of the tile (two values per P^T dword, in the order the k-steps use
+            // them) is issued in gap 8 + 7h/8; its row-sum add and the pack of its pair follow one gap LATER, so that no
+            // instruction waits for a transcendental's result (a dependent neighbour costs an s_nop)
+            static_for<(FP_V3_SKIP & 1) ? 0 : v3_exp_hi(m) - v3_exp_lo(m)>([&](auto HH) __attribute__((always_inline)) {
+                constexpr int h = v3_exp_lo(m) + HH, i = h >> 1, s4 = i >> 3, rb = (i >> 2) & 1, dw = i & 3;
+                constexpr int kb = s4 >> 1, j = (s4 & 1) * 8 + 2 * dw + (h & 1);
+                ev[h & 3] = __builtin_amdgcn_exp2f(S[CUR][rb][kb][j]);
+                asm volatile("" : "+v"(ev[h & 3]));                   // pinned to this gap (volatile asms keep their order)
+            });
+            if constexpr (m >= 1)
+                static_for<(FP_V3_SKIP & 1) ? 0 : v3_exp_hi(m - 1) - v3_exp_lo(m - 1)>([&](auto HH) __attribute__((always_inline)) {
+                    finish_exp(ic<v3_exp_lo(m - 1) + HH>{});
+                });
+            fence();
+        });
+        if constexpr (!(FP_V3_SKIP & 1)) finish_exp(ic<63>{});
+        // ---------------- did any P exceed 2^THR?  (then some row's max grew by more than THR: redo the tile)
+        pm = max(pm & 0xffffu, pm >> 16);
+        bool slow = first || !__all(pm <= THR_BITS);
+        if constexpr (FP_V3_SKIP & 128) slow = first;
+        if (slow) {
+            asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory"); // every MFMA of this iteration has retired
+            float alpha[2];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                float a0 = S[CUR][rb][0][0], a1 = S[CUR][rb][1][0];
+#pragma unroll
+                for (int j = 1; j < 16; ++j) {
+                    a0 = fmaxf(a0, S[CUR][rb][0][j]);
+                    a1 = fmaxf(a1, S[CUR][rb][1][j]);
+                }
+                float mx = fmaxf(a0, a1);
+                mx = fmaxf(mx, other_half(mx));
+                // the accumulators hold s - m: the row's max has grown by mx (if positive); rows that did not grow keep m
+                const float delta = first ? mx : fmaxf(mx, 0.f);
+                alpha[rb] = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+                l_run[rb] *= alpha[rb];
+                const float nm = negm[rb][0] - delta;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) negm[rb][j] = nm;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        S[CUR][rb][kb][j] -= delta;
+                        S[NXT][rb][kb][j] -= delta;                   // S(t+1) was accumulated onto the old -m
+                    }
+            }
+            rs[0] = rs[1] = 0.f;
+            static_for<32>([&](auto I_) __attribute__((always_inline)) {
+                constexpr int i = I_, s4 = i >> 3, rb = (i >> 2) & 1, dw = i & 3, kb = s4 >> 1, j = (s4 & 1) * 8 + 2 * dw;
+                const float e0 = __builtin_amdgcn_exp2f(S[CUR][rb][kb][j]);
+                const float e1 = __builtin_amdgcn_exp2f(S[CUR][rb][kb][j + 1]);
+                rs[rb] += e0 + e1;
+                union {
+                    unsigned u[4];
+                    bf16x8 v;
+                } pk;
+                pk.v = pf[rb][s4];
+                pk.u[dw] = cvt_pk_bf16(e0, e1);
+                pf[rb][s4] = pk.v;
+            });
+            if (!first) {                                             // O *= alpha (V(t-1) has been added)
+                static_for<128>([&](auto I_) __attribute__((always_inline)) {
+                    constexpr int i = I_, rb = (i >> 4) & 1;
+                    agpr_write<i>(agpr_read<i>() * alpha[rb]);
+                });
+            }
+#if defined(FP_V3_DIAG) && FP_V3_DIAG > 1
+            if (blockIdx.x == 8 && tid == 0) fp_attn_dbg[3] += 1;      // (-DFP_V3_DIAG=2: needs registers a full build lacks)
+#endif
+        }
+        l_run[0] += rs[0];
+        l_run[1] += rs[1];
+        k_tile += k_step;
+        v_tile += v_step;
+        kslot_wr = kslot_rd;                                          // K(t+4) goes where K(t+1) was
+        kslot_rd = kslot_rd == 2 ? 0 : kslot_rd + 1;
+        vslot_rd = vslot_nx;                                          // next: P.V reads V(t), prefetches V(t+1), loads V(t+3)
+        vslot_nx = (vslot_nx + 1) & 3;
+        vslot_wr = (vslot_wr + 1) & 3;
+        // The compiler does not know that the asm above writes S(t+1) with a 16-pass MFMA: a register copy it places
+        // behind this step (it does, on the way from the loop to the odd last step) must not come within 18 wait
+        // states of the last MFMA.  The end-of-tile check above covers about half of them.
+        asm volatile("s_nop 11" ::: "memory");
+        // ... and the registers of S(t+1) must stay allocated until the MFMAs have written them even where the value is
+        // dead (the last step: S(t+1) is never used, and the compiler handed its registers to the exp2 items while the
+        // MFMAs that write them were still in flight)
+        asm volatile("" ::"v"(S[NXT][0][0]), "v"(S[NXT][0][1]), "v"(S[NXT][1][0]), "v"(S[NXT][1][1]));
+    };
+#ifdef FP_V3_DIAG
+    if (blockIdx.x == 8 && tid == 0) {
+        fp_attn_dbg[4] = __builtin_amdgcn_s_memtime();
+        fp_attn_dbg[5] = __builtin_amdgcn_s_memrealtime();
+        fp_attn_dbg[3] = 0;
+    }
+#endif
+    {
+        int t = 0;
+        for (; t + 1 < nt; t += 2) {
+            step(t, ic<0>{});
+            step(t + 1, ic<1>{});
+        }
+        if (t < nt) step(t, ic<0>{});
+    }
+#ifdef FP_V3_DIAG
+    if (blockIdx.x == 8 && tid == 0) {
+        fp_attn_dbg[0] = __builtin_amdgcn_s_memtime() - fp_attn_dbg[4];
+        fp_attn_dbg[1] = __builtin_amdgcn_s_memrealtime() - fp_attn_dbg[5];
+        fp_attn_dbg[2] = (unsigned long long)nt;
+    }
+#endif
+    // ---- the last tile's P.V (its V tile landed before the last barrier; the prefetched fragments are read again)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(fr[0]), "v"(fr[1]), "v"(fr[2]));    // registers of the in-flight prefetch stay allocated until here
+    {
+        const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
+        static_for<4>([&](auto s4) __attribute__((always_inline)) {
+            static_for<4>([&](auto d) __attribute__((always_inline)) {
+                bf16x8 f;
+                rd_v(f, vbase, d, s4);
+                static_for<2>([&](auto rb) __attribute__((always_inline)) { mfma32_after<(d * 2 + rb) * 16, 0>(f, pf[rb][s4]); });
+            });
+        });
+    }
+    asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory");
+
+    float l_tot[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) l_tot[rb] = l_run[rb] + other_half(l_run[rb]);
+    if (nparts > 1) {                           // partial sweep: unnormalised O (fp32), running max and sum
+        static_for<2>([&](auto rb) __attribute__((always_inline)) {
+            const int row = wave * 64 + rb * 32 + r;
+            float* op = wsp + row * HD + 4 * hh;
+            static_for<4>([&](auto d) __attribute__((always_inline)) {
+                static_for<4>([&](auto g) __attribute__((always_inline)) {
+                    f32x4 v;
+                    static_for<4>([&](auto j) __attribute__((always_inline)) { v[(int)j] = agpr_read<(d * 2 + rb) * 16 + 4 * g + j>(); });
+                    *reinterpret_cast<f32x4*>(op + d * 32 + g * 8) = v;
+                });
+            });
+            if (hh == 0) {
+                wsp[256 * HD + row] = -negm[rb][0];
+                wsp[256 * HD + 256 + row] = l_tot[rb];
+            }
+        });
+        return;
+    }
+    static_for<2>([&](auto rb) __attribute__((always_inline)) {
+        const float inv = 1.f / l_tot[rb];
+        const int qrow_real = q0 + wave * 64 + rb * 32 + r;
+        if (qrow_real < seg_hi) {
+            bf16* op = O + (int64_t)qrow_real * o_rs + head * HD + 4 * hh;
+            static_for<4>([&](auto d) __attribute__((always_inline)) {
+                static_for<4>([&](auto g) __attribute__((always_inline)) {
+                    bf16x4 v;
+                    static_for<4>([&](auto j) __attribute__((always_inline)) {
+                        v[(int)j] = (bf16)(agpr_read<(d * 2 + rb) * 16 + 4 * g + j>() * inv);
+                    });
+                    *reinterpret_cast<bf16x4*>(op + d * 32 + g * 8) = v;
+                });
+            });
+        }
+    });
+}
+
 // Merge the `split` partial sweeps of each tail item: O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).
 // One workgroup = 16 query rows x 16 chunks of 8 head-dim columns.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ ws, bf16* __restrict__ O,
@@ -858,7 +1011,7 @@ int cu_count() {
 
 }  // namespace
 
-static int g_attn_variant = 1;      // 0: 8-wave ping-pong sweep | 1: one wave per SIMD, 64 query rows per wave
+static int g_attn_variant = 2;      // 1: second-generation sweep (S^T in AGPRs) | 2: third generation (S^T - m in VGPRs)
 extern "C" int fp_debug_attn_variant(int v) {
     const int old = g_attn_variant;
     if (v >= 0) g_attn_variant = v;
@@ -920,18 +1073,13 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
     // defer-max threshold 2^8: P <= 256 before the bf16 rounding (relative precision unchanged), the O rescale
     // runs only when a row's max grows by more than 8 in the log2 domain
-    if (g_attn_variant == 1) {
-        auto kern = attn_w64_kernel<8>;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KBUF);
+    {
+        const bool gen2 = g_attn_variant == 1;
+        auto kern = gen2 ? attn_w64_kernel<8> : attn_v3_kernel<8>;
+        const int lds = (gen2 ? 6 : 7) * KBUF;      // K ring of 3 slots + V ring of 3 (second generation) or 4 slots
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
-        kern<<<dim3((unsigned)grid), dim3(256), 6 * KBUF, (hipStream_t)stream>>>(
-            (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
-            o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
-    } else {
-        auto kern = attn_fwd_kernel<8>;
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * KBUF);
-        if (e != hipSuccess) return (int)e;
-        kern<<<dim3((unsigned)grid), dim3(512), 4 * KBUF, (hipStream_t)stream>>>(
+        kern<<<dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream>>>(
             (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
             o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
     }
@@ -995,9 +1143,8 @@ extern "C" int fp_attn_fwd_bf16_static(const void* q, const void* k, const void*
                        total_tokens, heads, head_dim, softmax_scale, ptr, fp_attn_static_scratch_bytes(), true, stream);
 }
 
-#ifdef FP_ATTN_DIAG
-// diagnostic build: per-wave cycle sums of the stamped tile loop
-extern "C" int fp_attn_dbg_read(unsigned long long* out64) {
-    return (int)hipMemcpyFromSymbol(out64, HIP_SYMBOL(fp_attn_dbg), sizeof(unsigned long long) * 64);
+#ifdef FP_V3_DIAG
+extern "C" int fp_attn_dbg_read(unsigned long long* out4) {
+    return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(fp_attn_dbg), sizeof(unsigned long long) * 4);
 }
 #endif

@@ -10,7 +10,8 @@ import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libframepack_hip.so")
+# FRAMEPACK_HIP_LIB: a differently built copy of the same library (timing-only probe builds, tools/attn_skip_probe.sh)
+LIB_PATH = os.environ.get("FRAMEPACK_HIP_LIB") or os.path.join(_HERE, "libframepack_hip.so")
 
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 

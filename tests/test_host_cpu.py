@@ -207,3 +207,39 @@ def test_w4_gemm_keeps_compiler_out_of_the_agprs(tmp_path):
                 assert "v_accvgpr_write" not in line and "v_accvgpr_mov" not in line, (cur, line)
                 assert "scratch_" not in line, (cur, line)
     assert seen >= 9          # bf16 x 5 epilogues, f16 dense x 2, f16 conv x 2
+
+
+def test_attention_kernels_keep_compiler_out_of_the_agprs(tmp_path):
+    """attn_fwd.hip keeps O^T and Q' in AGPRs addressed by number from inline asm; the compiler does not know they are
+    live.  A kernel that needs more than 256 VGPRs gets the excess parked in AGPRs by the register allocator (seen once:
+    spilled pointers, zeroed by the accumulator initialisation, faulted the GPU).  Compile the file to assembly with the
+    Makefile's flags and check, per attention kernel: every v_accvgpr_* instruction sits inside an inline-asm block,
+    nothing goes to scratch memory, and the VGPR count leaves the AGPR file alone."""
+    import re
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    src = os.path.join(ROOT, "framepack_amd", "csrc", "attn_fwd.hip")
+    if not os.path.exists(hipcc):
+        pytest.skip("needs hipcc")
+    mk = open(os.path.join(ROOT, "framepack_amd", "csrc", "Makefile")).read()
+    flags = re.search(r"^FLAGS_attn_fwd = (.*)$", mk, re.M).group(1).split()
+    out = tmp_path / "attn.s"
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", *flags, "-S", "--cuda-device-only", src, "-o",
+                    str(out)], check=True, capture_output=True)
+    text = out.read_text()
+    seen = 0
+    for m in re.finditer(r"^(_ZN\S*attn_(?:w64|v3)_kernel\S*):[^\n]*\n(.*?)^\s*\.amdhsa_kernel \1", text, re.S | re.M):
+        seen += 1
+        name, body = m.group(1), m.group(2)
+        in_asm = False
+        for line in body.splitlines():
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
+            elif not in_asm:
+                assert "v_accvgpr" not in line, (name, line)
+                assert "scratch_" not in line, (name, line)
+        assert int(re.search(re.escape(name) + r"\.num_vgpr, (\d+)", text).group(1)) <= 256
+        assert int(re.search(re.escape(name) + r"\.private_seg_size, (\d+)", text).group(1)) == 0
+    assert seen == 2

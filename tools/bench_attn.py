@@ -21,6 +21,9 @@ if os.environ.get("LAYOUT", "fused") == "fused":
 else:
     k, v, q = (torch.randn(S, d, generator=g, device=dev).to(torch.bfloat16) for _ in range(3))
 out = torch.empty(S, d, dtype=torch.bfloat16, device=dev)
+if os.environ.get("ATTN_VARIANT"):                     # 1: second-generation sweep, 2: third generation (default)
+    from framepack_amd import lib as _fplib
+    _fplib.load().fp_debug_attn_variant(int(os.environ["ATTN_VARIANT"]))
 attn = ops.attention_fp8 if os.environ.get("FP8") else ops.attention       # FP8=1: the e4m3 variant (quantisation included)
 for variant in range(int(os.environ.get("REPEAT", "2"))):
     for _ in range(3):
@@ -39,4 +42,12 @@ for variant in range(int(os.environ.get("REPEAT", "2"))):
     qh, kh, vh = q[rows][:, :128].double(), k[:, :128].double(), v[:, :128].double()
     ref = torch.softmax(qh @ kh.T / math.sqrt(128.0), -1) @ vh
     err = ((out[rows][:, :128].double() - ref).norm() / ref.norm()).item()
+    try:                                                    # probe builds (-DFP_V3_DIAG): in-kernel clock and cycles per tile
+        import ctypes
+        from framepack_amd import lib as _fplib
+        dbg = (ctypes.c_ulonglong * 4)()
+        if _fplib.load().fp_attn_dbg_read(dbg) == 0 and dbg[1] > 0:
+            print(f"   in-kernel: {dbg[0] / dbg[2]:.0f} cycles per tile over {dbg[2]} tiles, clock {dbg[0] / dbg[1] * 0.1:.2f} GHz, slow-path tiles {dbg[3]}", flush=True)
+    except AttributeError:
+        pass
     print(f"run {variant}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TF/s  ({fl / ms / 1e9 / 2500 * 100:.1f}% of 2.5 PF)  err {err:.2e}", flush=True)
