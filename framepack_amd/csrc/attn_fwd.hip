@@ -519,13 +519,6 @@ template <int QIDX> __device__ __forceinline__ void mfma_s_first_nw(f32x16& s, c
 template <int QIDX> __device__ __forceinline__ void mfma_s_next_nw(f32x16& s, const bf16x8& a) {
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%2:%3], %0" : "+v"(s) : "v"(a), "n"(QIDX), "n"(QIDX + 3));
 }
-// packed max of three dwords of two non-negative bf16 each, on their bit patterns read as f16 (same order; a pattern
-// that is a NaN as f16 - a bf16 above 2^120 - propagates, and compares above the threshold as an integer)
-__device__ __forceinline__ unsigned pk_max3(unsigned a, unsigned b, unsigned c) {
-    unsigned d;
-    asm volatile("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 constexpr int v3_exp_lo(int m) { return m < 8 ? 0 : (8 * (m - 8) + 6) / 7; }       // exps h with 8 + 7h/8 == m:
 constexpr int v3_exp_hi(int m) { return m < 7 ? 0 : (8 * (m - 7) + 6) / 7; }       // [lo, hi)
 // LDS-DMA instruction k (0..7) of a tile goes behind MFMA slot k: the gaps before the exp2 items start
@@ -542,6 +535,9 @@ constexpr int v3_dma_of_slot(int m) {
 // (V^T fragments 0..15 take two reads, K fragments 16..31 one, 32..34 are the next tile's first V^T fragments)
 constexpr int v3_reads_of(int f) { return f < 16 ? 2 : (f < 32 ? 1 : 2); }
 constexpr int v3_lgkm(int f) { return v3_reads_of(f + 1) + v3_reads_of(f + 2); }
+// One wait per TWO fragments: the first MFMA of an even fragment f waits for f and f + 1 (requested four MFMAs ago),
+// leaving only f + 2 in flight; the odd fragment's MFMAs then need no wait
+constexpr int v3_lgkm2(int f) { return v3_reads_of(f + 2); }
 
 template <int THR_LOG2>
 __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
@@ -554,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     constexpr int VRING = 3 * KBUF;
     constexpr int QBLK = 256;
     constexpr int QA = 128;                     // Q' fragments: a[QA + (rb * 8 + ks) * 4 ..]
-    constexpr unsigned THR_BITS = (unsigned)(127 + THR_LOG2) << 7;      // bf16 bit pattern of 2^THR
+    const float rs_limit = __builtin_ldexpf(1.f, THR_LOG2);               // a tile's row sums stay below 2^THR
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -722,9 +718,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
         const bool first = t == 0;
         float ev[4], rs[2] = {0.f, 0.f};     // exp ring: at most four values wait for their add / pack
-        unsigned pm = 0;
-        // row-sum add of exp h and, with the second value of a pair, the pack into its P^T dword; every second pair
-        // folds its dword and the previous one into the running packed max
+        // row-sum add of exp h and, with the second value of a pair, the pack into its P^T dword
         auto finish_exp = [&](auto H_) __attribute__((always_inline)) {
             constexpr int h = H_, i = h >> 1, s4 = i >> 3, rb = (i >> 2) & 1, dw = i & 3;
             rs[rb] += ev[h & 3];
@@ -739,7 +733,6 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
                 asm volatile("" : "+v"(pw));
                 pk.u[dw] = pw;
                 pf[rb][s4] = pk.v;
-                if constexpr (i & 1) pm = pk_max3(pm, pk.u[dw - 1], pw);
             }
         };
         if ((t0 + t == nt_all - 1) && (nkv & (KVBLK - 1))) {          // ragged last tile: keys past the end score -inf
@@ -763,13 +756,13 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             if constexpr (m < 32) {
                 constexpr int s4 = m >> 3, d = (m >> 1) & 3, rb = m & 1;
                 if constexpr (FP_V3_SKIP & 16) asm volatile("" ::"v"(fr[f & 3]), "v"(pf[rb][s4]));
-                else if constexpr (rb == 0) mfma32_after<(d * 2 + rb) * 16, v3_lgkm(f)>(fr[f & 3], pf[rb][s4]);
+                else if constexpr (rb == 0 && (f & 1) == 0) mfma32_after<(d * 2 + rb) * 16, v3_lgkm2(f)>(fr[f & 3], pf[rb][s4]);
                 else mfma32<(d * 2 + rb) * 16, false>(fr[f & 3], pf[rb][s4]);
             } else {
                 constexpr int q = m - 32, ks = q >> 2, kb = (q >> 1) & 1, rb = q & 1;
                 if constexpr (FP_V3_SKIP & 32) asm volatile("" : "+v"(S[NXT][rb][kb]) : "v"(fr[f & 3]));
-                else if constexpr (rb == 0 && ks == 0) mfma_s_first<QA + (rb * 8 + ks) * 4, v3_lgkm(f)>(S[NXT][rb][kb], fr[f & 3], negm[rb]);
-                else if constexpr (rb == 0) mfma_s_next<QA + (rb * 8 + ks) * 4, v3_lgkm(f)>(S[NXT][rb][kb], fr[f & 3]);
+                else if constexpr (rb == 0 && (f & 1) == 0 && ks == 0) mfma_s_first<QA + (rb * 8 + ks) * 4, v3_lgkm2(f)>(S[NXT][rb][kb], fr[f & 3], negm[rb]);
+                else if constexpr (rb == 0 && (f & 1) == 0) mfma_s_next<QA + (rb * 8 + ks) * 4, v3_lgkm2(f)>(S[NXT][rb][kb], fr[f & 3]);
                 else if constexpr (ks == 0) mfma_s_first_nw<QA + (rb * 8 + ks) * 4>(S[NXT][rb][kb], fr[f & 3], negm[rb]);
                 else mfma_s_next_nw<QA + (rb * 8 + ks) * 4>(S[NXT][rb][kb], fr[f & 3]);
             }
@@ -804,9 +797,9 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             fence();
         });
         if constexpr (!(FP_V3_SKIP & 1)) finish_exp(ic<63>{});
-        // ---------------- did any P exceed 2^THR?  (then some row's max grew by more than THR: redo the tile)
-        pm = max(pm & 0xffffu, pm >> 16);
-        bool slow = first || !__all(pm <= THR_BITS);
+        // ---------------- did a row's max grow by more than THR?  Then some P = exp2(s - m) of that row exceeds 2^THR and
+        // so does the tile's row sum (an overflow to inf or a NaN fails the test too): redo the tile on the slow path
+        bool slow = first || !__all(rs[0] <= rs_limit && rs[1] <= rs_limit);
         if constexpr (FP_V3_SKIP & 128) slow = first;
         if (slow) {
             asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory"); // every MFMA of this iteration has retired
@@ -1071,11 +1064,13 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
             split = 1;
     }
     const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
-    // defer-max threshold 2^8: P <= 256 before the bf16 rounding (relative precision unchanged), the O rescale
-    // runs only when a row's max grows by more than 8 in the log2 domain
+    // defer-max threshold.  Second generation: 2^8 (P <= 256 before the bf16 rounding, the O rescale runs only when a
+    // row's max grows by more than 8 in the log2 domain).  Third generation: 2^60 - the threshold only has to keep
+    // fp32 from overflowing (P <= 2^60, row sums and O below 2^60 * keys * |v|): bf16 and fp32 keep their relative
+    // precision at any magnitude, and a stale m never makes a P smaller than the true max would
     {
         const bool gen2 = g_attn_variant == 1;
-        auto kern = gen2 ? attn_w64_kernel<8> : attn_v3_kernel<8>;
+        auto kern = gen2 ? attn_w64_kernel<8> : attn_v3_kernel<60>;
         const int lds = (gen2 ? 6 : 7) * KBUF;      // K ring of 3 slots + V ring of 3 (second generation) or 4 slots
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;

@@ -260,6 +260,30 @@ def test_attention_max_jump_forces_rescale_branch():
     torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
 
 
+def test_attention_growth_beyond_the_deferred_max_threshold():
+    """The third-generation sweep keeps the first tile's row max as its reference and only moves it when a row's max
+    grows by more than 2^60 (its slow path: true max, O / l rescaled, the tile and the next tile's accumulators
+    shifted, P recomputed).  All queries lie near one direction b; key 100 = 5.9 b and key 500 = 6 b score ~96 and ~98
+    in the log2 domain against a first-tile max near 2: tile 1 must take the slow path, tile 7 then runs with a
+    reference that is stale by ~1.6, and both spikes carry weight in the result (0.24 : 0.76)."""
+    S, heads = 777, 2
+    g = torch.Generator("cpu").manual_seed(21)
+    b = torch.randn(heads, 128, generator=g)
+    b = b / b.norm(dim=-1, keepdim=True) * math.sqrt(128.0)
+    q = (b.unsqueeze(0) + 0.1 * torch.randn(S, heads, 128, generator=g)).reshape(S, -1).to(BF)
+    k = torch.randn(S, heads, 128, generator=g)
+    k[100], k[500] = 5.9 * b, 6.0 * b
+    k = k.reshape(S, -1).to(BF)
+    v = randn(S, heads * 128, seed=3)
+    got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
+    ref = attn_ref(q, k, v, heads)
+    assert torch.isfinite(got.float()).all()
+    w = (ref.float() - v[500].float()).norm() / v[500].float().norm()
+    assert w > 0.1                                   # not a one-hot softmax: key 100 matters too
+    assert rel_l2(got, ref) < 5e-3
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
+
+
 def test_attention_full_size_properties():
     """BASELINE config 2 shape (S = 19385, 24 heads): size-independent properties + sampled rows vs fp64."""
     S, heads = 19385, 24
