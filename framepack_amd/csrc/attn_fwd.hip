@@ -15,6 +15,7 @@
 //     V image: [d/32][key][64 B]                                      -> conflict-free tr reads.
 //   * Tails: rows are clamped on load, scores of keys past the segment end are masked to -inf in the
 //     last tile only, query rows past the end are not stored.  Nothing is padded in memory.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include "fp_common.h"
@@ -1004,11 +1005,11 @@ int cu_count() {
 
 }  // namespace
 
-static int g_attn_variant = 2;      // 1: second-generation sweep (S^T in AGPRs) | 2: third generation (S^T - m in VGPRs)
+// Diagnostics switch (same-process A/B, the tests of the generation that is not the default).  An atomic, read once
+// per launch: the reference calls forward() from a worker thread.
+static std::atomic<int> g_attn_variant{2};      // 1: second-generation sweep (S^T in AGPRs) | 2: third generation (S^T - m in VGPRs)
 extern "C" int fp_debug_attn_variant(int v) {
-    const int old = g_attn_variant;
-    if (v >= 0) g_attn_variant = v;
-    return old;
+    return v >= 0 ? g_attn_variant.exchange(v, std::memory_order_relaxed) : g_attn_variant.load(std::memory_order_relaxed);
 }
 
 // Library-internal (attn_fp8.hip): the merge of split tail items and the CU count behind the split decision.
@@ -1069,7 +1070,7 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     // fp32 from overflowing (P <= 2^60, row sums and O below 2^60 * keys * |v|): bf16 and fp32 keep their relative
     // precision at any magnitude, and a stale m never makes a P smaller than the true max would
     {
-        const bool gen2 = g_attn_variant == 1;
+        const bool gen2 = g_attn_variant.load(std::memory_order_relaxed) == 1;
         auto kern = gen2 ? attn_w64_kernel<8> : attn_v3_kernel<60>;
         const int lds = (gen2 ? 6 : 7) * KBUF;      // K ring of 3 slots + V ring of 3 (second generation) or 4 slots
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -1,12 +1,13 @@
 // K5: the nn.Linear of every DiT block, bf16 (kernel: gemm_pipeline.h).
+#include <atomic>
 #include "gemm_w4.h"
 
-static int g_variant = 1;      // 0: 8-wave ping-pong pipeline | 1: one wave per SIMD
-__attribute__((visibility("hidden"))) int fpi_gemm_variant() { return g_variant; }      // gemm_fp8.hip follows the same switch
+// Diagnostics switch (A/B measurements, the tests of the kernel generation that is not the default).  An atomic: the
+// reference calls forward() from a worker thread, and a launch reads the value exactly once.
+static std::atomic<int> g_variant_switch{1};      // 0: 8-wave ping-pong pipeline | 1: one wave per SIMD
+__attribute__((visibility("hidden"))) int fpi_gemm_variant() { return g_variant_switch.load(std::memory_order_relaxed); }      // gemm_fp8.hip follows the same switch
 extern "C" int fp_debug_gemm_variant(int v) {
-    const int old = g_variant;
-    if (v >= 0) g_variant = v;
-    return old;
+    return v >= 0 ? g_variant_switch.exchange(v, std::memory_order_relaxed) : g_variant_switch.load(std::memory_order_relaxed);
 }
 
 extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
@@ -17,6 +18,7 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
     if (int rc = check_dense(a, lda, a2, k1, w, ldw, bias, c, ldc, M, N, K, epilogue, gelu_from, resid, ldr, gate, a2_delta))
         return rc;
     if (M == 0) return 0;
+    const int g_variant = fpi_gemm_variant();           // read once per launch
     ConvGeom cg{};
     cg.gm = K >= 8192 ? -3 : (N >= 16384 ? 2 : 8);      // see ConvGeom::gm
     if (g_variant >> 4) cg.gm = (g_variant & 8) ? -(g_variant >> 4) : (g_variant >> 4);     // diagnostics: 1 | gm << 4 (| 8: column-major walk)

@@ -205,8 +205,12 @@ __global__ __launch_bounds__(256) void silu_gemv_kernel(const bf16* __restrict__
 // K10  TeaCache relative-L1 partial sums: acc[0] += sum|a-b|, acc[1] += sum|b|   (fp32 atomics)
 //      replaces ref hunyuan_video_packed.py:957-958 (two mean() passes + abs/sub temporaries)
 // ---------------------------------------------------------------------------------------------
+// Two deterministic stages (no atomics: the TeaCache decision must not depend on the order in which blocks retire):
+// every block writes its partial (sum |a - b|, sum |b|) to part[2 * block ..], then one wave adds the partials in
+// a fixed order.
+constexpr int REL_L1_MAX_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void rel_l1_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
-                                                     int64_t n8, float* __restrict__ acc) {
+                                                     int64_t n8, float* __restrict__ part) {
     float d = 0.f, m = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const bf16x8 av = reinterpret_cast<const bf16x8*>(a)[i];
@@ -220,16 +224,30 @@ __global__ __launch_bounds__(256) void rel_l1_kernel(const bf16* __restrict__ a,
     }
     d = wave_sum(d);
     m = wave_sum(m);
-    __shared__ float part[2][4];
+    __shared__ float sh[2][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) {
-        part[0][wv] = d;
-        part[1][wv] = m;
+        sh[0][wv] = d;
+        sh[1][wv] = m;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(acc, part[0][0] + part[0][1] + part[0][2] + part[0][3]);
-        atomicAdd(acc + 1, part[1][0] + part[1][1] + part[1][2] + part[1][3]);
+        part[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+__global__ __launch_bounds__(64) void rel_l1_final_kernel(const float* __restrict__ part, int nblocks,
+                                                          float* __restrict__ acc) {
+    float d = 0.f, m = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) {
+        d += part[2 * i];
+        m += part[2 * i + 1];
+    }
+    d = wave_sum(d);
+    m = wave_sum(m);
+    if (threadIdx.x == 0) {
+        acc[0] = d;
+        acc[1] = m;
     }
 }
 
@@ -308,15 +326,18 @@ extern "C" int fp_silu_gemv_bf16(const void* t, const void* W, const void* bias,
     return 0;
 }
 
-extern "C" int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc2, void* stream) {
-    FP_REQUIRE(a && b && acc2 && n >= 0 && n % 8 == 0 && aligned16(a) && aligned16(b));
+extern "C" int fp_rel_l1_acc_floats(void) { return 2 + 2 * REL_L1_MAX_BLOCKS; }
+
+extern "C" int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc, void* stream) {
+    FP_REQUIRE(a && b && acc && n >= 0 && n % 8 == 0 && aligned16(a) && aligned16(b));
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(acc2, 0, 2 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    if (n == 0) return 0;
     const int64_t n8 = n / 8;
-    const int grid = (int)((n8 + 255) / 256 < 1024 ? (n8 + 255) / 256 : 1024);
-    rel_l1_kernel<<<grid, 256, 0, st>>>((const bf16*)a, (const bf16*)b, n8, acc2);
+    const int grid = (int)((n8 + 255) / 256 < REL_L1_MAX_BLOCKS ? (n8 + 255) / 256 : REL_L1_MAX_BLOCKS);
+    if (grid > 0) {
+        rel_l1_kernel<<<grid, 256, 0, st>>>((const bf16*)a, (const bf16*)b, n8, acc + 2);
+        FP_CHECK_LAUNCH();
+    }
+    rel_l1_final_kernel<<<1, 64, 0, st>>>(acc + 2, grid, acc);
     FP_CHECK_LAUNCH();
     return 0;
 }

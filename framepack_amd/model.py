@@ -153,9 +153,38 @@ def _sinusoid_256(t: torch.Tensor) -> torch.Tensor:
     return torch.cat([torch.cos(ang), torch.sin(ang)], dim=-1)
 
 
+def _bf16_round(x: float) -> float:
+    """Round a host float to the nearest bf16 value (what a 0-dim bf16 tensor would hold)."""
+    return float(torch.tensor(x, dtype=torch.float32).to(BF16))
+
+
+class _MaskInfo:
+    """Step-invariant facts about an encoder_attention_mask, read back from the device ONCE per mask tensor (the
+    reference syncs on `mask.sum().item()` every step, ref :930): number of valid tokens, whether they form a prefix,
+    and the rows the refiner's attention runs over (valid tokens plus token 0, ref :337-340)."""
+
+    def __init__(self, mask: Optional[torch.Tensor]):
+        if mask is None:
+            self.n_valid, self.prefix, self.rows, self.invalid = None, True, None, None
+            return
+        m = mask.reshape(-1).bool()
+        host = m.cpu()
+        self.n_valid = int(host.sum())
+        self.prefix = bool(host[:self.n_valid].all())
+        att = host.clone()
+        att[0] = True                                                   # column 0 is visible to every row
+        self.n_att = int(att.sum())
+        self.att_prefix = bool(att[:self.n_att].all())
+        self.rows = None if self.att_prefix else att.nonzero().flatten().to(mask.device)
+        self.invalid = None if self.prefix and self.n_valid == m.numel() else (~host).nonzero().flatten().to(mask.device)
+
+
 class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
-    """Text-context embedder: 512 padded tokens, 2 small blocks, once per step (< 0.3 % of the FLOPs).
-    Runs on library GEMMs/SDPA through torch (plain, unfused, tiny) - not part of the hand-written path."""
+    """Text-context embedder: 512 padded tokens, 2 small blocks, once per step (< 0.3 % of the FLOPs).  Its linears
+    run on K5 (`fp_gemm_bf16`, gated residuals in the epilogue), its masked attention on K1: under the reference's
+    mask (outer AND of the key mask, column 0 forced visible, ref :337-340) a valid token attends to the valid tokens
+    plus token 0, and a padding token to token 0 alone - i.e. K1 over those rows, and v[0] for the padding rows.
+    LayerNorm (affine), SiLU and the two vector MLPs stay torch ops on [512, d] / [1, d] tensors."""
 
     def __init__(self, in_channels, heads, head_dim, num_layers, mlp_ratio=4.0):
         super().__init__()
@@ -164,8 +193,26 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
         self.time_text_embed = _TimeTextEmbed(d, in_channels, guidance=False)
         self.proj_in = nn.Linear(in_channels, d)
         self.token_refiner = _TokenRefinerStack(heads, head_dim, num_layers, mlp_ratio)
+        self._packed = None            # fused q|k|v weights per block (rebuilt after .to() / load_state_dict)
 
-    def forward(self, text, timestep, mask):
+    def _pack(self):
+        with torch.inference_mode(False), torch.no_grad():
+            P = []
+            for blk in self.token_refiner.refiner_blocks:
+                a = blk.attn
+                e = SimpleNamespace()
+                e.w_qkv = torch.cat([a.to_q.weight, a.to_k.weight, a.to_v.weight], dim=0).detach().to(BF16).contiguous()
+                e.b_qkv = torch.cat([a.to_q.bias, a.to_k.bias, a.to_v.bias], dim=0).detach().to(BF16).contiguous()
+                P.append(e)
+            self._packed = P
+        return P
+
+    def forward(self, text, timestep, mask, info: Optional[_MaskInfo] = None):
+        if not text.is_cuda:
+            raise RuntimeError("HunyuanVideoTokenRefiner (MI355X build) runs on the GPU only; there is no CPU fallback")
+        B, L, _ = text.shape
+        assert B == 1, "the packed forward feeds the refiner one sample at a time"
+        info = info or _MaskInfo(mask)
         if mask is None:
             pooled = text.mean(dim=1)
         else:
@@ -173,27 +220,35 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
             pooled = ((text * mf).sum(dim=1) / mf.sum(dim=1)).to(text.dtype)
         temb = self.time_text_embed.timestep_embedder(_sinusoid_256(timestep).to(pooled.dtype)) \
             + self.time_text_embed.text_embedder(pooled)
-        x = self.proj_in(text)
-        sa = None
-        if mask is not None:
-            B, L = mask.shape
-            m1 = mask.to(x.device).bool().view(B, 1, 1, L).expand(B, 1, L, L)
-            sa = (m1 & m1.transpose(2, 3)).clone()
-            sa[:, :, :, 0] = True                                      # ref :340
+        P = self._packed or self._pack()
         H = self.heads
-        for blk in self.token_refiner.refiner_blocks:
-            n1 = blk.norm1(x)
-            B, S, d = n1.shape
-            q = blk.attn.to_q(n1).view(B, S, H, -1).transpose(1, 2)
-            k = blk.attn.to_k(n1).view(B, S, H, -1).transpose(1, 2)
-            v = blk.attn.to_v(n1).view(B, S, H, -1).transpose(1, 2)
-            a = F.scaled_dot_product_attention(q, k, v, attn_mask=sa).transpose(1, 2).reshape(B, S, d)
-            a = blk.attn.to_out[0](a)
-            g_msa, g_mlp = blk.norm_out.linear(F.silu(temb)).chunk(2, dim=-1)
-            x = x + a * g_msa.unsqueeze(1)
-            ff = blk.ff.net[2](F.silu(blk.ff.net[0].proj(blk.norm2(x))))
-            x = x + ff * g_mlp.unsqueeze(1)
-        return x
+        d = self.proj_in.out_features
+        x = ops.gemm(text[0], self.proj_in.weight.detach(), self.proj_in.bias.detach())          # [L, d]
+        for blk, e in zip(self.token_refiner.refiner_blocks, P):
+            gates = ops.silu_gemv(temb[0], blk.norm_out.linear.weight.detach(), blk.norm_out.linear.bias.detach())
+            g_msa, g_mlp = gates[:d], gates[d:]
+            n1 = F.layer_norm(x, (d,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            qkv = ops.gemm(n1, e.w_qkv, e.b_qkv)                                                   # [L, q|k|v]
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            if mask is None:
+                att = ops.attention(q, k, v, H)
+            else:
+                att = v[0:1].expand(L, d).contiguous()            # a padding row sees token 0 only: softmax = 1
+                if info.att_prefix:
+                    n = info.n_att
+                    ops.attention(q[:n], k[:n], v[:n], H, out=att[:n])
+                else:
+                    sub = qkv.index_select(0, info.rows)
+                    att.index_copy_(0, info.rows, ops.attention(sub[:, :d], sub[:, d:2 * d], sub[:, 2 * d:], H))
+                if info.invalid is not None and not info.prefix:  # an invalid token 0 took part as a query above
+                    att.index_copy_(0, info.invalid, v[0:1].expand(info.invalid.numel(), d))
+            ops.gemm(att, blk.attn.to_out[0].weight.detach(), blk.attn.to_out[0].bias.detach(), out=x,
+                     epilogue=ops.EPI_GATE_RESIDUAL, resid=x, gate=g_msa)
+            n2 = F.layer_norm(x, (d,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            hdn = F.silu(ops.gemm(n2, blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach()))
+            ops.gemm(hdn, blk.ff.net[2].weight.detach(), blk.ff.net[2].bias.detach(), out=x,
+                     epilogue=ops.EPI_GATE_RESIDUAL, resid=x, gate=g_mlp)
+        return x.unsqueeze(0)
 
 
 class ClipVisionProjection(nn.Module):                  # ref :655-663
@@ -278,7 +333,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._rope_cache = RopeCache(rope_axes_dim, rope_theta)
         self._packed = None            # fused weight buffers, built lazily (see _pack)
         self._invariant = {}           # step-invariant results keyed by the identity of their inputs (see _cached)
-        self._ws = {}                  # activation workspaces keyed by (S, device)
+        self._ws = {}                  # grow-only activation backing store per device (see _workspace)
         self.taps = None               # optional dict: per-block outputs for parity tests
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
         self._sp_total = 0
@@ -334,8 +389,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         if not src.is_inference():
             stamp = src._version
         elif src.device.type == "cpu":
-            flat = src.reshape(-1)
-            stamp = tuple(flat[:: max(1, flat.numel() // 61)].double().tolist())
+            flat = src.reshape(-1)                        # small tensors (masks, indices) whole, large ones sampled
+            stamp = tuple(flat[:: 1 if flat.numel() <= 4096 else flat.numel() // 61].double().tolist())
         else:
             stamp = None
         key = (src.data_ptr(), tuple(src.shape), src.dtype, str(src.device), stamp)
@@ -345,6 +400,20 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         val = fn()
         self._invariant[slot] = (key, src, val)       # holding `src` keeps its address from being reused
         return val
+
+    def invalidate_packed(self):
+        """Drop the fused weight buffers (rebuilt on the next forward).  Call after editing a parameter IN PLACE
+        (a run-time LoRA swap): fp8, merged or dequantised weights are copied into the fused buffers, not
+        re-pointed, so such an edit is otherwise not seen.  `.to()`, `load_state_dict` and the fp8 switches do it
+        themselves."""
+        self._packed = None
+        self.context_embedder._packed = None
+
+    def invalidate_step_invariants(self):
+        """Drop the cross-step caches (clean-latent embeddings, image projection, mask facts).  They are keyed by
+        tensor identity and version counter; GPU tensors made under torch.inference_mode carry no version counter, so
+        after writing INTO such a tensor between steps call this (the section driver calls it per section)."""
+        self._invariant = {}
 
     def enable_fp8_compute(self, enable: bool = True):
         """Run the linears of the double/single blocks on the gfx950 fp8 MFMA (K6): weights held as e4m3 with a
@@ -403,13 +472,13 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
 
     # ---- weight fusion ---------------------------------------------------------------------
     def _apply(self, fn, *a, **k):                      # .to() / .cuda() / .half(): fused buffers go stale
-        self._packed = None
+        self.invalidate_packed()
         self._invariant = {}
         self._ws = {}
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._packed = None
+        self.invalidate_packed()
         self._invariant = {}
         return super().load_state_dict(*a, **k)
 
@@ -497,20 +566,32 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         return P
 
     def _workspace(self, S: int, device):
-        key = (S, str(device))
-        ws = self._ws.get(key)
-        if ws is None:
-            d = self.inner_dim
-            m = self.transformer_blocks[0].ff.net[0].proj.out_features if len(self.transformer_blocks) else 4 * d
-            self._ws = {}                                     # one shape at a time (sections keep S fixed)
-            ws = SimpleNamespace(X=torch.empty((S, d), dtype=BF16, device=device),
-                                 N=torch.empty((S, d), dtype=BF16, device=device),
-                                 Y=torch.empty((S, 3 * d + m), dtype=BF16, device=device),
-                                 acc=torch.zeros((2,), dtype=torch.float32, device=device))
+        """Views [S, ...] of a grow-only backing store per device: a negative prompt (another text length, so another
+        S) alternates with the positive one every step without freeing and re-allocating ~1 GB twice per step."""
+        key = str(device)
+        back = self._ws.get(key)
+        d = self.inner_dim
+        m = self.transformer_blocks[0].ff.net[0].proj.out_features if len(self.transformer_blocks) else 4 * d
+        if back is None or back.rows < S:
+            rows = S if back is None else max(S, back.rows)
+            self._ws.pop(key, None)
+            back = None                                   # release before the larger allocation
+            n_mod = (12 * len(self.transformer_blocks) + 3 * len(self.single_transformer_blocks) + 2) * d
+            back = SimpleNamespace(rows=rows, X=torch.empty((rows, d), dtype=BF16, device=device),
+                                   N=torch.empty((rows, d), dtype=BF16, device=device),
+                                   Y=torch.empty((rows, 3 * d + m), dtype=BF16, device=device),
+                                   mods=torch.empty((n_mod,), dtype=BF16, device=device),
+                                   acc=ops.rel_l1_acc(device), views={})
             if self.fp8_compute:                              # e4m3 image of one GEMM's A operand + row scales
-                ws.Q = torch.empty((S * (d + m),), dtype=ops.FP8, device=device)
-                ws.QS = torch.empty((S,), dtype=torch.float32, device=device)
-            self._ws[key] = ws
+                back.Q = torch.empty((rows * (d + m),), dtype=ops.FP8, device=device)
+                back.QS = torch.empty((rows,), dtype=torch.float32, device=device)
+            self._ws[key] = back
+        ws = back.views.get(S)
+        if ws is None:
+            ws = SimpleNamespace(X=back.X[:S], N=back.N[:S], Y=back.Y[:S], mods=back.mods, acc=back.acc)
+            if self.fp8_compute:
+                ws.Q, ws.QS = back.Q, back.QS
+            back.views[S] = ws
         return ws
 
     # ---- packing of the input streams (ref :822-879) ----------------------------------------
@@ -675,19 +756,23 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         temb = self.time_text_embed.timestep_embedder(_sinusoid_256(timestep).to(pooled_projections.dtype)) \
             + self.time_text_embed.guidance_embedder(_sinusoid_256(guidance).to(pooled_projections.dtype)) \
             + self.time_text_embed.text_embedder(pooled_projections)
-        encoder_attention_mask = encoder_attention_mask.to(dev)
-        ctx = self.context_embedder(encoder_hidden_states, timestep, encoder_attention_mask)
-        mask = encoder_attention_mask
+        # facts about the mask (valid count, prefix or not): read back once per mask tensor, not once per step
+        if encoder_attention_mask is None:
+            minfo = _MaskInfo(None)
+        else:
+            minfo = self._cached("mask_info", encoder_attention_mask, lambda: _MaskInfo(encoder_attention_mask.to(dev)))
+            encoder_attention_mask = encoder_attention_mask.to(dev)
+        ctx = self.context_embedder(encoder_hidden_states, timestep, encoder_attention_mask, minfo)
+        text_len = ctx.shape[1] if minfo.n_valid is None else minfo.n_valid
         if self.image_projection is not None:
             assert image_embeddings is not None, "You must use image embeddings!"
             extra = self._cached("image_projection", image_embeddings,
                                  lambda: self.image_projection(image_embeddings))
             ctx = torch.cat([extra, ctx], dim=1)                     # image tokens before text (ref :922-923)
-            mask = torch.cat([torch.ones((B, extra.shape[1]), dtype=mask.dtype, device=mask.device), mask], dim=1)
+            text_len += extra.shape[1]                               # its mask is all ones (ref :924)
 
         assert B == 1          # forward() feeds a batch one sample at a time
-        text_len = int(mask.sum().item())                           # ref :930 (one host sync per step)
-        ctx = ctx[:, :text_len]
+        ctx = ctx[:, :text_len]                                      # ref :930-931, without the per-step host sync
 
         # packed image tokens straight into the residual-stream buffer
         n_img = self._count_image_tokens(hidden_states, clean_latents, clean_latent_indices, clean_latents_2x,
@@ -723,7 +808,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         ws.X[Si:].copy_(ctx[0])
 
         # all AdaLN modulations of this step: one GEMV over the concatenated modulation weights
-        mods = ops.silu_gemv(temb[0], P.w_mod, P.b_mod)
+        mods = ops.silu_gemv(temb[0], P.w_mod, P.b_mod, out=ws.mods)
 
         if self.taps is not None:
             self.taps["packed_hidden"], self.taps["rope"] = ws.X[:Si].clone(), rope
@@ -739,13 +824,14 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                 self.accumulated_rel_l1_distance = 0
                 self.cache_misses += 1
             else:
-                acc_t = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc) if Si > 0 else ws.acc.zero_()
+                acc_t = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc) if Si > 0 else ws.acc[:2].zero_()
                 if self.sp_world > 1:                       # identical decision on every rank
                     import torch.distributed as dist
                     dist.all_reduce(acc_t, group=self.sp_group)
                 acc = acc_t.tolist()                                           # host sync (ref :958)
                 n = n_img * d                               # elements over all ranks
-                curr = (acc[0] / n) / (acc[1] / n + 1e-8)
+                # the reference takes both means and their quotient in bf16 (0-dim bf16 tensors, ref :957-958)
+                curr = _bf16_round(_bf16_round(acc[0] / n) / _bf16_round(_bf16_round(acc[1] / n) + 1e-8))
                 self.accumulated_rel_l1_distance += self.teacache_rescale_func(curr)
                 should_calc = self.accumulated_rel_l1_distance >= self.rel_l1_thresh
                 if should_calc:

@@ -25,9 +25,19 @@ def _stream(t: torch.Tensor) -> int:
 
 
 def _dev(*ts: Optional[torch.Tensor]) -> None:
+    """Every tensor on the GPU, and on the CURRENT HIP device: a kernel launches on the current device whatever
+    stream handle it is given, so a tensor of another GPU would be read through the wrong device's queue."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("framepack_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                               f"wrap the call in `with torch.cuda.device({t.device.index}):`")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -103,12 +113,14 @@ _ATTN_WS = {}
 
 
 def _attn_workspace(device: torch.device) -> torch.Tensor:
-    """Per-device scratch for the attention kernel's split last round (allocated once, by the caller: the
-    library itself allocates nothing).  Calls on one device share it, so they must be stream-ordered."""
-    ws = _ATTN_WS.get(device)
+    """Scratch for the attention kernel's split last round, one per (device, stream): calls on one stream are
+    ordered, calls on different streams get different buffers (allocated once each, by the caller: the library
+    itself allocates nothing)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _ATTN_WS.get(key)
     if ws is None:
         ws = torch.empty((_lib.load().fp_attn_workspace_bytes(),), dtype=torch.uint8, device=device)
-        _ATTN_WS[device] = ws
+        _ATTN_WS[key] = ws
     return ws
 
 
@@ -203,15 +215,22 @@ def silu_gemv(t: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
+def rel_l1_acc(device) -> torch.Tensor:
+    """Result + scratch buffer of `rel_l1` (fp_rel_l1_acc_floats() floats)."""
+    return torch.zeros((_lib.load().fp_rel_l1_acc_floats(),), dtype=torch.float32, device=device)
+
+
 def rel_l1(a: torch.Tensor, b: torch.Tensor, acc: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K10: returns device float32 [2] = (sum|a-b|, sum|b|)."""
+    """K10: returns a device float32 view [2] = (sum|a-b|, sum|b|); deterministic (two stages, no atomics).
+    acc: a buffer from `rel_l1_acc` to reuse."""
     _dev(a, b, acc)
     assert a.is_contiguous() and b.is_contiguous() and a.numel() == b.numel() and a.dtype == BF16 and b.dtype == BF16
     if acc is None:
-        acc = torch.empty((2,), dtype=torch.float32, device=a.device)
+        acc = rel_l1_acc(a.device)
+    assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.numel() >= _lib.load().fp_rel_l1_acc_floats()
     _lib.check(_lib.load().fp_rel_l1_bf16(a.data_ptr(), b.data_ptr(), a.numel(), acc.data_ptr(), _stream(a)),
                "fp_rel_l1_bf16")
-    return acc
+    return acc[:2]
 
 
 EPI_BIAS, EPI_GELU, EPI_GELU_FROM, EPI_GATE_RESIDUAL, EPI_RESIDUAL = 0, 1, 2, 3, 4

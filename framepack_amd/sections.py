@@ -52,6 +52,16 @@ def soft_append_bcthw(history: torch.Tensor, current: torch.Tensor, overlap: int
     return torch.cat([history[:, :, :-overlap], blended, current[:, :, overlap:]], dim=2).to(history)
 
 
+def pick_ui_section(i_section: int, keys, total_sections: int):
+    """ref worker.py:354-367, 404-418 (get_section_prompt / get_section_latent): the per-section maps are keyed by UI
+    section number, counted from the START of the video, while the loop generates from the END: processing step
+    i_section is UI section `total_sections - i_section - 1`, and it takes the entry of the largest key <= that number
+    (the nearest earlier UI section).  Returns that key, or None when no key qualifies."""
+    reversed_index = total_sections - i_section - 1
+    valid = [k for k in keys if k <= reversed_index]
+    return max(valid) if valid else None
+
+
 @dataclass
 class SectionResult:
     history_latents: torch.Tensor              # [1, 16, generated + 19, h, w] fp32 (CPU), newest section first
@@ -65,13 +75,19 @@ def generate_sections(sample_fn: Callable, decode_fn: Optional[Callable], start_
                       width: int, total_latent_sections: int, latent_window_size: int = 9, seed: int = 31337,
                       end_latent: Optional[torch.Tensor] = None, end_frame_strength: float = 1.0,
                       one_frame_inference: bool = False, section_latents: Optional[Dict[int, torch.Tensor]] = None,
-                      sample_kwargs: Optional[dict] = None, on_section: Optional[Callable] = None) -> SectionResult:
+                      sample_kwargs: Optional[dict] = None, on_section: Optional[Callable] = None,
+                      section_sample_kwargs: Optional[Dict[int, dict]] = None) -> SectionResult:
     """The reference's section loop (ref worker.py:325-332, 430-720).
 
     sample_fn(frames=..., generator=..., latent_indices=..., clean_latents=..., ... , **sample_kwargs)
         -> generated latents [1, 16, T, h, w]            (sample_hunyuan's contract)
     decode_fn(latents) -> pixels [1, 3, 4(T-1)+1, 8h, 8w] (vae_decode's contract), or None to skip decoding
-    section_latents: optional per-section replacement of the start latent (ref get_section_latent)."""
+    section_latents: optional replacements of the start latent keyed by UI section number (ref get_section_latent,
+        worker.py:404-426): a processing step uses the entry of the nearest earlier UI section (`pick_ui_section`).
+    section_sample_kwargs: optional per-UI-section overrides of `sample_kwargs`, chosen by the same rule - the place of
+        the reference's per-section prompts (ref get_section_prompt, worker.py:354-401: prompt_embeds,
+        prompt_embeds_mask, prompt_poolers of another prompt; encoding the text is the caller's job, the text encoders
+        are outside this path)."""
     rnd = torch.Generator("cpu").manual_seed(seed)
     num_frames = latent_window_size * 4 - 3
     history_latents = torch.zeros((1, 16, 1 + 2 + 16, height // 8, width // 8), dtype=torch.float32)
@@ -84,7 +100,12 @@ def generate_sections(sample_fn: Callable, decode_fn: Optional[Callable], start_
         if is_first and end_latent is not None:                                   # ref :450-459
             history_latents[:, :, 0:1] = end_latent * end_frame_strength if end_frame_strength != 1.0 else end_latent
         idx = section_indices(latent_padding, latent_window_size, one_frame_inference)
-        current = start_latent if not section_latents or i_section not in section_latents else section_latents[i_section]
+        key = pick_ui_section(i_section, section_latents.keys(), len(paddings)) if section_latents else None
+        current = start_latent if key is None else section_latents[key]
+        per_section = dict(sample_kwargs or {})
+        pkey = pick_ui_section(i_section, section_sample_kwargs.keys(), len(paddings)) if section_sample_kwargs else None
+        if pkey is not None:
+            per_section.update(section_sample_kwargs[pkey])
         clean_pre = current.to(history_latents)
         clean_post, clean_2x, clean_4x = history_latents[:, :, :1 + 2 + 16].split([1, 2, 16], dim=2)
         kw = dict(clean_latents=torch.cat([clean_pre, clean_post], dim=2), clean_latents_2x=clean_2x,
@@ -93,7 +114,7 @@ def generate_sections(sample_fn: Callable, decode_fn: Optional[Callable], start_
         if one_frame_inference:                                                   # ref :468-481
             kw["clean_latents_2x"] = kw["clean_latents_4x"] = None
             frames = 1
-        generated = sample_fn(width=width, height=height, frames=frames, generator=rnd, **kw, **(sample_kwargs or {}))
+        generated = sample_fn(width=width, height=height, frames=frames, generator=rnd, **kw, **per_section)
         if is_last and not one_frame_inference:                                   # ref :655-656
             generated = torch.cat([start_latent.to(generated), generated], dim=2)
         total += int(generated.shape[2])
@@ -107,6 +128,7 @@ def generate_sections(sample_fn: Callable, decode_fn: Optional[Callable], start_
                 history_pixels = soft_append_bcthw(decode_fn(real[:, :, :n_lat]).cpu(), history_pixels,
                                                    latent_window_size * 4 - 3)
         log.append(dict(section=i_section, latent_padding=latent_padding, is_last=is_last, total_latent_frames=total,
+                        ui_section_latent=key, ui_section_kwargs=pkey,
                         pixel_frames=None if history_pixels is None else int(history_pixels.shape[2])))
         if on_section is not None:
             on_section(log[-1], history_pixels)

@@ -96,10 +96,13 @@ int fp_gate_residual_bf16(void* x, int64_t x_row_stride, const void* y, int64_t 
 int fp_silu_gemv_bf16(const void* t, const void* W, const void* bias, void* out,
                       int in_dim, int out_dim, int apply_silu, void* stream);
 
-/* K10 TeaCache statistic: acc2[0] = sum |a - b| (difference rounded to bf16 first), acc2[1] = sum |b|.
- * Replaces hunyuan_video_packed.py:957-958.  a,b: n bf16 elements (n % 8 == 0); acc2: 2 floats (device),
- * zeroed by the call. */
-int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc2, void* stream);
+/* K10 TeaCache statistic: acc[0] = sum |a - b| (difference rounded to bf16 first), acc[1] = sum |b|.
+ * Replaces hunyuan_video_packed.py:957-958.  a,b: n bf16 elements (n % 8 == 0).  acc: fp_rel_l1_acc_floats() floats
+ * of device memory; the first two receive the sums, the rest is scratch for the per-block partials.  Two
+ * deterministic stages, no atomics: the same inputs give the same bits (the TeaCache decision compares the result
+ * with a threshold). */
+int fp_rel_l1_acc_floats(void);
+int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc, void* stream);
 
 /* K5  C = epilogue(A . W^T + bias): the nn.Linear of every block (hunyuan_video_packed.py:119-121,
  * 133-135, 154-156, 167-169, 552, 570 and diffusers FeedForward at :646-647).
@@ -176,8 +179,10 @@ int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int toke
 
 /* ---- diagnostics (no counterpart in the reference) --------------------------------------------------------
  * Select the kernel generation used by fp_gemm_bf16 / fp_attn_fwd_bf16 for same-process A/B measurements
- * (tools/ab_model.py): 0 = first generation (8 waves per workgroup), 1 = second (one wave per SIMD; default).
- * v < 0 only queries.  Returns the previous value.  Process-wide, not thread-safe.
+ * (tools/ab_model.py) and for the tests of the generation that is not the default.  GEMM: 0 = first generation (8 waves
+ * per workgroup), 1 = second (one wave per SIMD; default).  Attention: 1 = second generation (S^T in AGPRs), 2 = third
+ * (S^T - m accumulated in VGPRs; default).  v < 0 only queries.  Returns the previous value.  Process-wide; the
+ * switches are atomics read once per launch, so a change never tears a launch in flight on another thread.
  * fp_gemm_fp8_bf16 follows the GEMM switch too.  For the GEMM, v >> 4 (when non-zero) overrides the number of row
  * tiles per group of the tile walk (tools/gemm_xp.py scans it: FP_GEMM_VARIANT = 1 + 16 * gm). */
 int fp_debug_gemm_variant(int v);

@@ -370,6 +370,9 @@ class TeaCacheState:
     misses: int = 0
     queries: int = 0
     trace: list = field(default_factory=list)
+    # dtype the statistic is taken in.  None = the dtype of the run (the reference's behaviour: a bf16 run subtracts,
+    # averages and divides in bf16, ref :957-958).  An fp32 run that checks a bf16 product path sets torch.bfloat16.
+    stat_dtype: Optional[torch.dtype] = None
 
 
 def dit_forward(P, cfg: DiTConfig, hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
@@ -425,7 +428,8 @@ def dit_forward(P, cfg: DiTConfig, hidden_states, timestep, encoder_hidden_state
             tc.acc = 0.0
             tc.misses += 1
         else:
-            rel = ((mod - tc.prev_mod).abs().mean() / (tc.prev_mod.abs().mean() + 1e-8)).item()
+            cur_s, prev_s = (mod, tc.prev_mod) if tc.stat_dtype is None else (mod.to(tc.stat_dtype), tc.prev_mod.to(tc.stat_dtype))
+            rel = ((cur_s - prev_s).abs().mean() / (prev_s.abs().mean() + 1e-8)).item()
             tc.acc += float(TEACACHE_POLY(rel))
             calc = tc.acc >= tc.rel_l1_thresh
             if calc:

@@ -205,6 +205,15 @@ def test_gemm_rejects_bad_arguments():
 
 
 # ------------------------------------------------------------------ K1
+@pytest.fixture(params=[1, 2], ids=["gen2_agpr_scores", "gen3_vgpr_scores"])
+def attn_variant(request):
+    """Both attention sweeps the library holds (fp_debug_attn_variant), the default restored afterwards."""
+    from framepack_amd import lib as fplib
+    old = fplib.load().fp_debug_attn_variant(request.param)
+    yield request.param
+    fplib.load().fp_debug_attn_variant(old)
+
+
 def attn_ref(q, k, v, heads):
     S = q.shape[0]
     return O.attention_reference_f64(q.view(S, heads, 128), k.view(S, heads, 128), v.view(S, heads, 128)).reshape(S, -1)
@@ -212,14 +221,14 @@ def attn_ref(q, k, v, heads):
 
 @pytest.mark.parametrize("S,heads", [(1, 1), (63, 2), (64, 1), (65, 3), (255, 1), (256, 2), (257, 1), (777, 3),
                                      (1408 + 766, 2), (2 * 256 + 64, 24)])
-def test_attention_single_segment(S, heads):
+def test_attention_single_segment(S, heads, attn_variant):
     d = heads * 128
     q, k, v = randn(S, d, seed=1), randn(S, d, seed=2), randn(S, d, seed=3)
     got = ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), heads)
     assert rel_l2(got, attn_ref(q, k, v, heads)) < 5e-3
 
 
-def test_attention_strided_fused_buffer_and_alias():
+def test_attention_strided_fused_buffer_and_alias(attn_variant):
     """q,k,v as column ranges of one [S, k|v|q|mlp] buffer (the single-stream layout); o written over q."""
     S, heads = 900, 2
     d = heads * 128
@@ -231,7 +240,7 @@ def test_attention_strided_fused_buffer_and_alias():
     assert torch.equal(bd[:, :2 * d].cpu(), buf[:, :2 * d]) and torch.equal(bd[:, 3 * d:].cpu(), buf[:, 3 * d:])
 
 
-def test_attention_varlen_segments():
+def test_attention_varlen_segments(attn_variant):
     """cu_seqlens as ref hunyuan_video_packed.py:63-77 builds them: valid tokens and the padding tail of
     each sample are separate segments; an empty segment is allowed."""
     heads, d = 2, 256
@@ -245,7 +254,7 @@ def test_attention_varlen_segments():
             assert rel_l2(got[a:b], attn_ref(q[a:b], k[a:b], v[a:b], heads)) < 5e-3
 
 
-def test_attention_max_jump_forces_rescale_branch():
+def test_attention_max_jump_forces_rescale_branch(attn_variant):
     """Spike one key against every query in a late tile so the running max jumps there
     (the data-dependent rescale branch), plus large-magnitude scores."""
     S, heads = 640, 1
@@ -260,7 +269,7 @@ def test_attention_max_jump_forces_rescale_branch():
     torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
 
 
-def test_attention_growth_beyond_the_deferred_max_threshold():
+def test_attention_growth_beyond_the_deferred_max_threshold(attn_variant):
     """The third-generation sweep keeps the first tile's row max as its reference and only moves it when a row's max
     grows by more than 2^60 (its slow path: true max, O / l rescaled, the tile and the next tile's accumulators
     shifted, P recomputed).  All queries lie near one direction b; key 100 = 5.9 b and key 500 = 6 b score ~96 and ~98
@@ -309,7 +318,7 @@ def test_attention_full_size_properties():
         assert rel_l2(o[rows][:, sl], p @ vh) < 6e-3
 
 
-def test_attention_split_last_round_matches_unsplit_sweeps():
+def test_attention_split_last_round_matches_unsplit_sweeps(attn_variant):
     """261 work items on a 256-CU chip: the 5 items of the last round are swept as 8 KV ranges each and merged
     (fp_attn_fwd_bf16 with a workspace).  Their rows, and rows of unsplit items, against an fp32 reference; the
     ragged last query block and last KV tile are inside the split items."""

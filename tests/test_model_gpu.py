@@ -89,6 +89,67 @@ def test_tiny_forward_matches_reference_golden(tiny, golden_dir):
     assert rel_l2(got, torch.from_numpy(G["E_out_bf16"])) < 2 * TOL
 
 
+@pytest.mark.parametrize("mask_kind", ["prefix", "scattered", "token0_masked", "all_valid", "none"])
+def test_token_refiner_on_library_kernels_matches_oracle_for_any_mask(tiny, mask_kind):
+    """ref :326-345: the refiner's attention mask is the outer AND of the key mask with column 0 forced visible.  The
+    product runs it as K1 over (valid tokens + token 0) and v[0] for padding rows; every one of the 512 rows must
+    equal the oracle's masked SDPA, for prefix masks (what the worker produces) and for any other pattern."""
+    m, P32 = tiny
+    cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
+    g = torch.Generator("cpu").manual_seed(9)
+    text = torch.randn(1, 512, 4096, generator=g).to(BF)
+    t = torch.tensor([730.0]).to(BF)
+    mask = torch.zeros(1, 512, dtype=torch.bool)
+    if mask_kind == "prefix":
+        mask[:, :37] = True
+    elif mask_kind == "scattered":
+        mask[0, torch.randperm(512, generator=g)[:100]] = True
+        mask[0, 0] = True
+    elif mask_kind == "token0_masked":
+        mask[:, 5:60] = True
+    elif mask_kind == "all_valid":
+        mask[:] = True
+    else:
+        mask = None
+    ref = O.token_refiner(P32, cfg, text.float(), t.float(), mask)
+    got = m.context_embedder(text.to(DEV), t.to(DEV), None if mask is None else mask.to(DEV))
+    assert got.shape == ref.shape
+    assert rel_l2(got, ref) < TOL
+    if mask is not None:
+        valid = mask[0]
+        assert rel_l2(got[0, valid], ref[0, valid]) < TOL and rel_l2(got[0, ~valid], ref[0, ~valid]) < TOL or valid.all()
+
+
+def test_forward_reads_the_mask_back_once_per_mask_tensor(tiny):
+    """ref :930 syncs on mask.sum().item() every step; the product reads the mask's facts back once per mask tensor
+    (cross-step cache) and recomputes when another mask arrives."""
+    from framepack_amd import model as M
+    m, P32 = tiny
+    cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
+    kw = synthetic.make_inputs(dtype=BF, **CASES["config1"])
+    dkw = to_dev(kw)
+    made = {"n": 0}
+    real = M._MaskInfo
+
+    class Counting(real):
+        def __init__(self, mask):
+            made["n"] += 1
+            super().__init__(mask)
+    M._MaskInfo = Counting
+    m._invariant = {}
+    try:
+        a = m(return_dict=False, **dkw)[0]
+        b = m(return_dict=False, **dkw)[0]
+        assert made["n"] == 1 and torch.equal(a, b)
+        kw2 = synthetic.make_inputs(dtype=BF, **dict(CASES["config1"], n_text=11))
+        c = m(return_dict=False, **to_dev(kw2))[0]
+        assert made["n"] == 2
+        assert rel_l2(c, O.dit_forward(P32, cfg, **to_f32(kw2))) < TOL
+    finally:
+        M._MaskInfo = real
+        m._invariant = {}
+
+
 def test_fp32_output_head_flag(tiny):
     m, P32 = tiny
     cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
@@ -116,7 +177,7 @@ def test_teacache_schedule_matches_oracle(tiny):
     m, P32 = tiny
     cfg = O.DiTConfig(**synthetic.CONFIG_TINY)
     kw = synthetic.make_inputs(dtype=BF, **CASES["config1"])
-    tc = O.TeaCacheState(enable=True, num_steps=6, rel_l1_thresh=0.15)
+    tc = O.TeaCacheState(enable=True, num_steps=6, rel_l1_thresh=0.15, stat_dtype=BF)   # the product's dtype
     m.initialize_teacache(enable_teacache=True, num_steps=6, rel_l1_thresh=0.15)
     try:
         for s in [1.0, 0.98, 0.95, 0.9, 0.6, 0.2]:

@@ -92,3 +92,31 @@ def test_one_frame_inference_path():
     res = S.generate_sections(sample_fn, decode_fn, torch.zeros(1, 16, 1, 4, 4), 32, 32, 7, one_frame_inference=True)
     assert len(calls) == 1 and calls[0]["T"] == 1 and calls[0]["two"] is None and calls[0]["latent_indices"] == [9]
     assert res.total_generated_latent_frames == 1 and res.history_pixels.shape[2] == 1
+
+
+def test_section_maps_are_keyed_by_ui_section_and_take_the_nearest_earlier_entry():
+    """ref worker.py:354-367, 404-418: maps are keyed by UI section (counted from the start of the video); processing
+    step i of n is UI section n - i - 1 and uses the largest key <= that.  Sparse map {0, 2} over 4 sections:
+    steps 0, 1 (UI sections 3, 2) take key 2, steps 2, 3 (UI sections 1, 0) take key 0."""
+    assert [S.pick_ui_section(i, {0, 2}, 4) for i in range(4)] == [2, 2, 0, 0]
+    assert [S.pick_ui_section(i, {1}, 3) for i in range(3)] == [1, 1, None]
+    assert S.pick_ui_section(0, [], 3) is None
+    calls = []
+    seen_kw = []
+
+    def sample_fn(width, height, frames, generator, clean_latents, tag=None, **kw):
+        calls.append(float(clean_latents[0, 0, 0, 0, 0]))
+        seen_kw.append(tag)
+        return torch.zeros(1, 16, (frames + 3) // 4, height // 8, width // 8)
+
+    start = torch.full((1, 16, 1, 4, 4), -1.0)
+    lat = {0: torch.full((1, 16, 1, 4, 4), 10.0), 2: torch.full((1, 16, 1, 4, 4), 12.0)}
+    res = S.generate_sections(sample_fn, None, start, 32, 32, 4, section_latents=lat, sample_kwargs=dict(tag="default"),
+                              section_sample_kwargs={2: dict(tag="late")})
+    assert calls == [12.0, 12.0, 10.0, 10.0]
+    assert seen_kw == ["late", "late", "default", "default"]
+    assert [s["ui_section_latent"] for s in res.sections] == [2, 2, 0, 0]
+    # a map with no key at or before a UI section leaves the start latent in place
+    calls.clear()
+    S.generate_sections(sample_fn, None, start, 32, 32, 3, section_latents={1: lat[2]})
+    assert calls == [12.0, 12.0, -1.0]
