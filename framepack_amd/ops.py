@@ -399,25 +399,49 @@ def conv3d_causal_strided(x: torch.Tensor, weight: torch.Tensor, bias: Optional[
     return out
 
 
-def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-6,
-              silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """GroupNorm (+SiLU) over a channels-last volume x [..., C] fp16 (all leading dims are the group's extent)."""
-    _dev(x, gamma, beta, out)
-    assert x.is_contiguous() and x.dtype == F16 and gamma.dtype == F16 and beta.dtype == F16
+_GN_WS = {}
+
+
+def groupnorm_stats(x: torch.Tensor, groups: int, eps: float = 1e-6, stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm statistics of a channels-last volume x [..., C] fp16: fp32 [2 * groups] = (mean, rstd) per group,
+    two deterministic stages.  The partials' workspace is kept per (device, stream, C): no allocation per call."""
+    _dev(x, stats)
+    assert x.is_contiguous() and x.dtype == F16
     C = x.shape[-1]
     rows = x.numel() // C
     lib = _lib.load()
-    ws = torch.empty((lib.fp_groupnorm_workspace_floats(C),), dtype=torch.float32, device=x.device)
-    stats = torch.empty((2 * groups,), dtype=torch.float32, device=x.device)
+    key = (x.device, torch.cuda.current_stream(x.device).cuda_stream, C)
+    ws = _GN_WS.get(key)
+    if ws is None:
+        ws = _GN_WS[key] = torch.empty((lib.fp_groupnorm_workspace_floats(C),), dtype=torch.float32, device=x.device)
+    if stats is None:
+        stats = torch.empty((2 * groups,), dtype=torch.float32, device=x.device)
+    assert stats.dtype == torch.float32 and stats.numel() == 2 * groups and stats.is_contiguous()
     _lib.check(lib.fp_groupnorm_stats_f16(x.data_ptr(), rows, C, groups, eps, ws.data_ptr(), stats.data_ptr(),
                                           _stream(x)), "fp_groupnorm_stats_f16")
+    return stats
+
+
+def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int,
+                    silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = f(GroupNorm(x; stats) * gamma + beta), f = SiLU or identity; out may be x."""
+    _dev(x, stats, gamma, beta, out)
+    assert x.is_contiguous() and x.dtype == F16 and gamma.dtype == F16 and beta.dtype == F16
+    C = x.shape[-1]
+    rows = x.numel() // C
     if out is None:
         out = torch.empty_like(x)
     assert out.shape == x.shape and out.is_contiguous() and out.dtype == F16
-    _lib.check(lib.fp_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), rows, C, groups, stats.data_ptr(),
-                                          gamma.data_ptr(), beta.data_ptr(), int(silu), _stream(x)),
+    _lib.check(_lib.load().fp_groupnorm_apply_f16(x.data_ptr(), out.data_ptr(), rows, C, groups, stats.data_ptr(),
+                                                  gamma.data_ptr(), beta.data_ptr(), int(silu), _stream(x)),
                "fp_groupnorm_apply_f16")
     return out
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float = 1e-6,
+              silu: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GroupNorm (+SiLU) over a channels-last volume x [..., C] fp16 (all leading dims are the group's extent)."""
+    return groupnorm_apply(x, groupnorm_stats(x, groups, eps), gamma, beta, groups, silu, out)
 
 
 def softmax_framecausal_(scores: torch.Tensor, tokens_per_frame: int, scale: float) -> torch.Tensor:

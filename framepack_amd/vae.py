@@ -154,6 +154,66 @@ class DecoderOutput(SimpleNamespace):
     pass
 
 
+class _Bands:
+    """Spatial tiling of one decode over the ranks of a group: rank r owns a band of consecutive rows of H (at every
+    resolution of the decoder: a band of n latent rows is 8 n image rows).  What crosses band borders:
+      * a 3x3x3 convolution reads one row above and one below its output row (of its own input resolution): before
+        every convolution the border rows are exchanged with the two neighbours (`extend`), the convolution runs on
+        the extended band and the rows computed from the halo alone are cut off.  At the top and bottom of the volume
+        there is no neighbour and the kernel's clamp is the replicate padding, as on one GPU;
+      * GroupNorm statistics are global over (T, H, W): every rank reduces its own rows, the per-group (sum, sum of
+        squares, count) are all-reduced (3 x groups doubles) and every rank normalises with the same (mean, rstd);
+      * the mid-block attention sees all tokens: the k | v bands are all-gathered into (t, h, w) order, each rank
+        keeps the queries of its band.
+    Time is not split (the causal convolutions need every earlier frame) and neither is W."""
+
+    def __init__(self, group, H: int):
+        import torch.distributed as dist
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        if H < self.world:
+            raise ValueError(f"{H} latent rows cannot be tiled over {self.world} ranks")
+        base, rem = divmod(H, self.world)
+        self.sizes = [base + (r < rem) for r in range(self.world)]            # latent rows per rank
+        self.lo = sum(self.sizes[:self.rank])
+        self.hi = self.lo + self.sizes[self.rank]
+        self.top, self.bot = self.rank > 0, self.rank < self.world - 1
+
+    def extend(self, x: torch.Tensor) -> torch.Tensor:
+        """[T, Hb, W, C] -> [T, (1) + Hb + (1), W, C]: the neighbours' border rows around the band."""
+        from .comm import neighbour_exchange
+        fu, fd = neighbour_exchange(x[:, :1] if self.top else None, x[:, -1:] if self.bot else None, self.group)
+        parts = ([fu] if self.top else []) + [x] + ([fd] if self.bot else [])
+        return torch.cat(parts, dim=1) if len(parts) > 1 else x
+
+    def crop(self, y_ext: torch.Tensor, up_h: int) -> torch.Tensor:
+        """Cut the rows computed from a halo row off a convolution's output (up_h output rows per input row)."""
+        r0 = up_h if self.top else 0
+        r1 = y_ext.shape[1] - (up_h if self.bot else 0)
+        return y_ext[:, r0:r1].contiguous() if (self.top or self.bot) else y_ext
+
+    def global_stats(self, stats: torch.Tensor, n_local: int, eps: float) -> torch.Tensor:
+        """Per-group (mean, rstd) of this rank's rows -> (mean, rstd) over all ranks' rows.  The moments are rebuilt
+        from (mean, rstd) in fp64: sum = mean n, sum of squares = (var + mean^2) n."""
+        from .comm import all_reduce_sum
+        st = stats.view(-1, 2).double()
+        mean, rstd = st[:, 0], st[:, 1]
+        var = (1.0 / (rstd * rstd) - eps).clamp_min(0.0)
+        pack = torch.stack([mean * n_local, (var + mean * mean) * n_local, torch.full_like(mean, float(n_local))])
+        all_reduce_sum(pack, self.group)
+        n = pack[2]
+        m = pack[0] / n
+        v = (pack[1] / n - m * m).clamp_min(0.0)
+        return torch.stack([m, 1.0 / torch.sqrt(v + eps)], dim=1).float().reshape(-1).contiguous()
+
+    def gather_rows(self, x: torch.Tensor, rows_per_latent_row: int) -> torch.Tensor:
+        """[T, Hb, W, C] bands of all ranks -> the whole volume [T, H, W, C] on every rank."""
+        from .comm import all_gather_padded
+        parts = all_gather_padded(x.permute(1, 0, 2, 3).contiguous(), [n * rows_per_latent_row for n in self.sizes],
+                                  self.group)
+        return torch.cat(parts, dim=0).permute(1, 0, 2, 3)
+
+
 class DiagonalGaussianDistribution:
     """What `vae.encode(x).latent_dist` offers in diffusers: parameters [B, 2C, ...] = (mean | logvar), the log
     variance clamped to [-30, 20]; `sample(generator)` = mean + std * N(0, 1), `mode()` = mean."""
@@ -358,8 +418,91 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         out = ops.gemm(o, W[name + ".o.w"], W[name + ".o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
         return out.reshape(T, H, Wd, C)
 
+    # ---- the same decoder on a band of rows per rank (enable_tile_parallel) --------------------------------------
+    GN_EPS = 1e-6
+
+    def _gn_b(self, B: _Bands, W, name: str, x: torch.Tensor, silu: bool = True, out: Optional[torch.Tensor] = None):
+        g = self.config.norm_num_groups
+        st = B.global_stats(ops.groupnorm_stats(x, g, self.GN_EPS), x.numel() // g, self.GN_EPS)
+        return ops.groupnorm_apply(x, st, W[name + ".g"], W[name + ".b"], g, silu, out)
+
+    def _conv_b(self, B: _Bands, W, name: str, x: torch.Tensor, up=(1, 1, 1), resid: Optional[torch.Tensor] = None):
+        xe = B.extend(x)
+        re = None
+        if resid is not None:                    # the skip is added in the kernel's epilogue, as on one GPU: give it
+            re = resid                           # the extended shape (halo rows: anything finite, they are cut off)
+            if B.top or B.bot:
+                re = torch.zeros((resid.shape[0], xe.shape[1] * up[1], resid.shape[2], resid.shape[3]), dtype=F16,
+                                 device=resid.device)
+                r0 = up[1] if B.top else 0
+                re[:, r0:r0 + resid.shape[1]] = resid
+        return B.crop(ops.conv3d_causal(xe, W[name + ".w"], W[name + ".b"], up=up, resid=re), up[1])
+
+    def _resnet_b(self, B: _Bands, W, name: str, h: torch.Tensor) -> torch.Tensor:
+        a = self._gn_b(B, W, name + ".norm1", h)
+        c1 = self._conv_b(B, W, name + ".conv1", a)
+        del a
+        self._gn_b(B, W, name + ".norm2", c1, out=c1)
+        if (name + ".sc.w") in W:
+            res = ops.gemm(h.reshape(-1, h.shape[-1]), W[name + ".sc.w"], W[name + ".sc.b"]).reshape(*h.shape[:3], -1)
+        else:
+            res = h
+        return self._conv_b(B, W, name + ".conv2", c1, resid=res)
+
+    def _attention_b(self, B: _Bands, W, h: torch.Tensor, H: int, name: str = "attn") -> torch.Tensor:
+        """Mid-block attention with the queries of this rank's band against all keys (frame-causal: a token sees the
+        tokens of frames <= its own).  k | v of every band are gathered into (t, h, w) order."""
+        T, Hb, Wd, C = h.shape
+        Sl, S = T * Hb * Wd, T * H * Wd
+        Sp = _pad_to(S, 64)
+        x = h.reshape(Sl, C)
+        hn = self._gn_b(B, W, name + ".gn", h, silu=False).reshape(Sl, C)
+        qkv = ops.gemm(hn, W[name + ".qkv.w"], W[name + ".qkv.b"])
+        kv = B.gather_rows(qkv[:, C:].reshape(T, Hb, Wd, 2 * C), 1).reshape(S, 2 * C)
+        k_all = torch.zeros(Sp, C, dtype=F16, device=h.device)                # rows >= S stay zero
+        k_all[:S] = kv[:, :C]
+        vt = torch.zeros(C, Sp, dtype=F16, device=h.device)
+        vt[:, :S] = kv[:, C:].t()
+        scores = torch.empty(Sl, Sp, dtype=F16, device=h.device)
+        ops.gemm(qkv[:, :C], k_all, None, out=scores)                         # q (pre-scaled) . k^T
+        for t in range(T):       # rows of frame t see the first (t + 1) H W keys; the kernel zeroes the other columns
+            ops.softmax_framecausal_(scores[t * Hb * Wd:(t + 1) * Hb * Wd], (t + 1) * H * Wd, 1.0)
+        o = ops.gemm(scores, vt, None)
+        del scores
+        out = ops.gemm(o, W[name + ".o.w"], W[name + ".o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
+        return out.reshape(T, Hb, Wd, C)
+
+    def _decode_tile_bands(self, z: torch.Tensor) -> torch.Tensor:
+        """`_decode_tile` with H split into one band of rows per rank; every rank returns the whole frames."""
+        W = self._prepare()
+        cfg = self.config
+        lat = cfg.latent_channels
+        _, _, T, H, Wd = z.shape
+        B = _Bands(self._tp_group, H)
+        x = torch.zeros(T, B.hi - B.lo, Wd, W["pq.w"].shape[0], dtype=F16, device=z.device)
+        x[..., :lat] = z[0, :, :, B.lo:B.hi].permute(1, 2, 3, 0).to(F16)
+        x = ops.gemm(x.reshape(-1, x.shape[-1]), W["pq.w"], W["pq.b"]).reshape(x.shape)
+        h = self._conv_b(B, W, "conv_in", x)
+        h = self._resnet_b(B, W, "mid.0", h)
+        if cfg.mid_block_add_attention:
+            h = self._attention_b(B, W, h, H)
+        h = self._resnet_b(B, W, "mid.1", h)
+        scale = 1
+        for i, ub in enumerate(self.decoder.up_blocks):
+            for j in range(len(ub.resnets)):
+                h = self._resnet_b(B, W, f"up.{i}.{j}", h)
+            if ub.factor is not None:
+                h = self._conv_b(B, W, f"up.{i}.us", h, up=ub.factor)
+                scale *= ub.factor[1]
+        self._gn_b(B, W, "norm_out", h, out=h)
+        y = self._conv_b(B, W, "conv_out", h)                                  # [To, scale * Hb, Wo, 8]
+        y = B.gather_rows(y[..., :cfg.out_channels].contiguous(), scale)
+        return y.permute(3, 0, 1, 2).unsqueeze(0)
+
     def _decode_tile(self, z: torch.Tensor) -> torch.Tensor:
         """z: [1, latent, T, H, W] on the GPU -> [1, 3, 4(T-1)+1, 8H, 8W] fp16."""
+        if getattr(self, "_tp_group", None) is not None:
+            return self._decode_tile_bands(z)
         W = self._prepare()
         cfg = self.config
         lat = cfg.latent_channels
@@ -441,6 +584,16 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         the single-GPU framewise decode."""
         import torch.distributed as dist
         self._wp_group = group if group is not None else dist.group.WORLD
+
+    def enable_tile_parallel(self, group=None) -> None:
+        """Multi-GPU decode by spatial tiles with halo exchange (new design; the reference is single-GPU, BASELINE.json
+        north_star): every decode window is split into one band of rows per rank (`_Bands`), border rows are exchanged
+        before every convolution, GroupNorm statistics are all-reduced, the mid-block's keys and values all-gathered.
+        Unlike `enable_window_parallel` (whole windows dealt to ranks: at most one rank per window busy, 3 windows in a
+        33-frame section) every rank works on every window, and the result equals the single-GPU decode up to the
+        rounding of the GroupNorm moments.  Every rank calls decode() with the same latents and gets the same frames."""
+        import torch.distributed as dist
+        self._tp_group = group if group is not None else dist.group.WORLD
 
     def _framewise(self, z: torch.Tensor, tile_fn) -> torch.Tensor:
         """diffusers' _temporal_tiled_decode: windows of t_min+1 latent frames at stride t_stride, the first
