@@ -336,6 +336,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ws = {}                  # grow-only activation backing store per device (see _workspace)
         self.taps = None               # optional dict: per-block outputs for parity tests
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
+        self.sp_chunks = None          # head chunks per exchange (None: ulysses.pick_chunks decides)
         self._sp_total = 0
         self.fp8_compute = False       # block linears on the fp8 MFMA (enable_fp8_compute)
         self.fp8_attention = False     # joint attention with e4m3 Q, K, P, V (enable_fp8_attention)
@@ -443,7 +444,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         else:
             from .ulysses import ulysses_attention
             ulysses_attention(q, k, v, self._sp_total, self.heads, self.head_dim,
-                              lambda jq, jk, jv, h, o: attn(jq, jk, jv, h, out=o), self.sp_group, out=q)
+                              lambda jq, jk, jv, h, o: attn(jq, jk, jv, h, out=o), self.sp_group, out=q,
+                              chunks=self.sp_chunks)
 
     @property
     def device(self):

@@ -31,60 +31,89 @@ def row_shard(n_rows: int, world: int, rank: int):
     return n, lo, min(n, n_rows - lo)
 
 
-def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group) -> None:
-    """all_to_all_single; gloo has no GPU all-to-all, so GPU tensors on a gloo group (the 2-process test on one GPU)
-    are staged through host memory.  RCCL takes the direct path."""
+class _Done:
+    def wait(self):
+        return None
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, group, async_op: bool = False):
+    """all_to_all_single -> a handle with .wait().  gloo has no GPU all-to-all, so GPU tensors on a gloo group (the
+    2-process test on one GPU) are staged through host memory, synchronously.  RCCL takes the direct path; with
+    async_op the exchange runs on the communicator's stream and `wait()` makes the current stream wait for it."""
     if inp.is_cuda and dist.get_backend(group) == "gloo":
         o = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(o, inp.cpu(), group=group)
         out.copy_(o)
-    else:
-        dist.all_to_all_single(out, inp, group=group)
+        return _Done()
+    w = dist.all_to_all_single(out, inp, group=group, async_op=async_op)
+    return w if async_op else _Done()
+
+
+def pick_chunks(n_total: int, heads_local: int, cus: int = 256) -> int:
+    """Two head chunks (the second chunk's exchange runs under the first chunk's attention, the first chunk's return
+    under the second's attention) when each chunk still fills the chip: a chunk has heads_local / 2 heads x
+    ceil(S / 256) work items of 256 query rows, and a partly filled round costs a whole sweep.  At S = 19 385 that is
+    P = 2 and 4 (6 and 3 heads per chunk: 456 and 228 items); at P = 8 the 3 local heads stay one exchange."""
+    if heads_local % 2 == 0 and (heads_local // 2) * -(-n_total // 256) >= (3 * cus) // 4:
+        return 2
+    return 1
 
 
 def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total: int, heads: int, head_dim: int,
-                      attn_fn: Callable, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      attn_fn: Callable, group=None, out: Optional[torch.Tensor] = None,
+                      chunks: Optional[int] = None) -> torch.Tensor:
     """q, k, v: [n, heads*head_dim] views (row-strided ok) holding this rank's run of the packed sequence (row_shard;
     padding rows included).  n_total = S, the valid rows over all ranks.  Returns / fills `out` (same shape; may be q)
     with the attention output of the local rows for all heads (padding rows: zeros).
 
-    attn_fn(q, k, v, heads_local, out) -> out   over [S, heads_local*head_dim] views."""
+    attn_fn(q, k, v, heads_local, out) -> out   over [S, heads_local*head_dim] views.
+    chunks: head chunks exchanged and attended one after the other so that communication overlaps attention
+    (default: `pick_chunks`)."""
     world = dist.get_world_size(group)
     if heads % world != 0:
         raise ValueError(f"{heads} heads do not divide over {world} ranks")
     hl = heads // world
-    hw = hl * head_dim
     n = q.shape[0]
     if n != row_shard(n_total, world, 0)[0]:
         raise ValueError(f"{n} local rows do not match {n_total} rows over {world} ranks")
+    if chunks is None:
+        chunks = pick_chunks(n_total, hl)
+    if hl % chunks != 0:
+        raise ValueError(f"{hl} local heads do not split into {chunks} chunks")
+    hc = hl // chunks
+    hwc = hc * head_dim
     dev, dt = q.device, q.dtype
-
-    # ---- forward exchange: [n, P, (q|k|v), hw] -> per-peer contiguous [P, n, 3*hw]; received = the sequence in order
-    send = torch.stack([q.reshape(n, world, hw), k.reshape(n, world, hw), v.reshape(n, world, hw)],
-                       dim=2).permute(1, 0, 2, 3).contiguous()
-    joint = torch.empty((world * n, 3 * hw), dtype=dt, device=dev)
-    _all_to_all(joint, send.view(world * n, 3 * hw), group)
-
-    # ---- attention over the valid tokens, local head group (output over q)
     S = n_total
-    o = attn_fn(joint[:S, :hw], joint[:S, hw:2 * hw], joint[:S, 2 * hw:], hl, joint[:S, :hw])
 
-    # ---- inverse exchange: to peer p its rows, my head group
-    back = torch.empty((world * n, hw), dtype=dt, device=dev)
-    back[:S] = o
-    if S < world * n:
-        back[S:].zero_()
-    recv = torch.empty((world, n, hw), dtype=dt, device=dev)
-    _all_to_all(recv.view(world * n, hw), back, group)
+    # ---- pack: [n, P, chunk, (q|k|v), hwc] -> [chunk, P, n, 3*hwc]: per chunk one contiguous slice per peer; what a
+    #      peer receives is the packed sequence in order (rank order = sequence order)
+    send = torch.stack([t.reshape(n, world, chunks, hwc) for t in (q, k, v)], dim=3).permute(2, 1, 0, 3, 4).contiguous()
+    joints = [torch.empty((world * n, 3 * hwc), dtype=dt, device=dev) for _ in range(chunks)]
+    fwd = [_all_to_all(joints[c], send[c].view(world * n, 3 * hwc), group, async_op=chunks > 1) for c in range(chunks)]
+
+    # ---- per chunk: attention over the valid tokens of the local head chunk, written straight into the send buffer
+    #      of the inverse exchange (rows past S: padding, zeros), which then runs under the next chunk's attention
+    recvs, inv = [], []
+    for c in range(chunks):
+        fwd[c].wait()
+        back = torch.empty((world * n, hwc), dtype=dt, device=dev)
+        attn_fn(joints[c][:S, :hwc], joints[c][:S, hwc:2 * hwc], joints[c][:S, 2 * hwc:], hc, back[:S])
+        if S < world * n:
+            back[S:].zero_()
+        recv = torch.empty((world, n, hwc), dtype=dt, device=dev)
+        inv.append(_all_to_all(recv.view(world * n, hwc), back, group, async_op=chunks > 1))
+        recvs.append(recv)
+
     if out is None:
         out = torch.empty((n, heads * head_dim), dtype=dt, device=dev)
-    # recv[p] = head group p of my rows  ->  out[:, p*hw:(p+1)*hw]
-    out_v = out.unflatten(1, (world, hw)) if out.is_contiguous() else None
-    if out_v is not None:
-        out_v.copy_(recv.permute(1, 0, 2))
-    else:
-        for p in range(world):
-            out[:, p * hw:(p + 1) * hw] = recv[p]
+    # recvs[c][p] = heads [p*hl + c*hc, +hc) of my rows  ->  out[:, (p*chunks + c)*hwc : +hwc]
+    for c in range(chunks):
+        inv[c].wait()
+        if out.is_contiguous():
+            out.unflatten(1, (world, chunks, hwc))[:, :, c].copy_(recvs[c].permute(1, 0, 2))
+        else:
+            for p in range(world):
+                out[:, (p * chunks + c) * hwc:(p * chunks + c + 1) * hwc] = recvs[c][p]
     return out
 
 

@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, teacache, fp8_attention, ret):
+def _worker(rank, world, port, case, teacache, fp8_attention, heads, chunks, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,7 +26,7 @@ def _worker(rank, world, port, case, teacache, fp8_attention, ret):
         from framepack_amd import synthetic
         from framepack_amd.model import HunyuanVideoTransformer3DModelPacked
         bf, dev = torch.bfloat16, "cuda:0"
-        m = HunyuanVideoTransformer3DModelPacked(**synthetic.CONFIG_TINY).to(bf)
+        m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_TINY, num_attention_heads=heads)).to(bf)
         synthetic.init_synthetic_(dict(m.state_dict()), seed=0)
         m = m.to(dev).eval()
         if fp8_attention:
@@ -45,6 +45,7 @@ def _worker(rank, world, port, case, teacache, fp8_attention, ret):
             return outs, (m.cache_hits, m.cache_misses) if teacache else None
         single, c1 = run()
         m.enable_sequence_parallel()
+        m.sp_chunks = chunks
         sharded, c2 = run()
         err = max(((a - b).norm() / b.norm()).item() for a, b in zip(sharded, single))
         ret[rank] = (err, c1 == c2)
@@ -58,12 +59,15 @@ CASES = {
 }
 
 
-@pytest.mark.parametrize("case,teacache,fp8_attention", [("config1", False, False), ("odd_text", False, False),
-                                                         ("config1", True, False), ("config1", False, True)])
-def test_sequence_parallel_forward_equals_single_gpu(case, teacache, fp8_attention):
+@pytest.mark.parametrize("case,teacache,fp8_attention,heads,chunks", [
+    ("config1", False, False, 2, None), ("odd_text", False, False, 2, None), ("config1", True, False, 2, None),
+    ("config1", False, True, 2, None),
+    ("config1", False, False, 4, 2)])        # two head chunks per rank: the overlapped exchange of ulysses.py
+def test_sequence_parallel_forward_equals_single_gpu(case, teacache, fp8_attention, heads, chunks):
     world = 2
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), CASES[case], teacache, fp8_attention, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), CASES[case], teacache, fp8_attention, heads, chunks, ret), nprocs=world,
+             join=True)
     assert len(ret) == world
     for err, same_counts in ret.values():
         # same kernels on the same values; only the order of the keys inside the attention (and the tile split of

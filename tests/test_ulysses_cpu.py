@@ -21,7 +21,7 @@ def _attn(q, k, v, heads, out):
     return out
 
 
-def _worker(rank, world, port, n_img_total, n_txt, heads, strided, ret):
+def _worker(rank, world, port, n_img_total, n_txt, heads, strided, chunks, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,9 +38,10 @@ def _worker(rank, world, port, n_img_total, n_txt, heads, strided, ret):
         if strided:                                   # q|k|v as column ranges of one buffer, output over q
             buf = torch.cat([lq0, lk0, lv0, torch.zeros(n, 64)], dim=1)
             lq, lk, lv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
-            got = ulysses.ulysses_attention(lq, lk, lv, S, heads, 128, _attn, out=lq)
+            got = ulysses.ulysses_attention(lq, lk, lv, S, heads, 128, _attn, out=lq, chunks=chunks)
         else:
-            got = ulysses.ulysses_attention(lq0.contiguous(), lk0.contiguous(), lv0.contiguous(), S, heads, 128, _attn)
+            got = ulysses.ulysses_attention(lq0.contiguous(), lk0.contiguous(), lv0.contiguous(), S, heads, 128, _attn,
+                                            chunks=chunks)
         err = (got[:valid] - full[lo:lo + valid]).abs().max().item() if valid else 0.0
         gathered = ulysses.gather_rows(got.contiguous())[:S]
         err2 = (gathered - full).abs().max().item()
@@ -55,14 +56,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_img,n_txt,heads,strided", [(2, 64, 9, 2, False), (2, 50, 0, 4, True),
-                                                           (4, 40, 7, 4, True), (4, 41, 2, 4, False),
-                                                           (2, 63, 10, 2, True), (4, 2, 1, 4, False)])
-def test_ulysses_attention_equals_unsharded(world, n_img, n_txt, heads, strided):
+@pytest.mark.parametrize("world,n_img,n_txt,heads,strided,chunks", [
+    (2, 64, 9, 2, False, 1), (2, 50, 0, 4, True, 1), (4, 40, 7, 4, True, 1), (4, 41, 2, 4, False, 1),
+    (2, 63, 10, 2, True, 1), (4, 2, 1, 4, False, 1),
+    (2, 63, 10, 4, True, 2), (2, 40, 7, 8, False, 2), (4, 41, 2, 8, True, 2)])      # two head chunks, overlapped exchanges
+def test_ulysses_attention_equals_unsharded(world, n_img, n_txt, heads, strided, chunks):
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), n_img, n_txt, heads, strided, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_img, n_txt, heads, strided, chunks, ret), nprocs=world, join=True)
     assert len(ret) == world
     assert max(ret.values()) < 1e-5
+
+
+def test_chunking_keeps_the_chip_full():
+    """Two chunks only where half the local heads still give about a chip's worth of 256-row work items."""
+    assert ulysses.pick_chunks(19385, 12) == 2 and ulysses.pick_chunks(19385, 6) == 2      # P = 2, 4
+    assert ulysses.pick_chunks(19385, 3) == 1                                              # P = 8: 3 heads, odd
+    assert ulysses.pick_chunks(1408, 2) == 1                                               # tiny sequences: one exchange
 
 
 def test_row_shard():
