@@ -26,8 +26,8 @@
 
 // attn_fwd.hip: merge of the split tail items (same partial layout: O[256][128] unnormalised, m[256], l[256], fp32)
 int fpi_attn_cu_count();
-int fpi_attn_combine(const float* ws, void* o, int64_t o_rs, int total, int heads, int nqb, int nwg_full, int split,
-                     int ntail, hipStream_t st);
+int fpi_attn_combine(const float* ws, void* o, int64_t o_rs, const int* cu_seqlens, int total, int heads, int nqb,
+                     int nwg_full, int split, int ntail, hipStream_t st);
 
 namespace {
 
@@ -138,18 +138,27 @@ __global__ __launch_bounds__(256) void quant_qk_kernel(const bf16* __restrict__ 
     }
 }
 
-// vt8: block = (tile of 64 keys, head); through an LDS tile [64 keys][128 d] of e4m3
+// vt8: block = (segment * tps + tile of 64 keys, head); through an LDS tile [64 keys][128 d] of e4m3.  Every segment
+// has its own grid of `tps` tiles starting at its first row (tile t of segment s covers rows seg_lo + 64 t ..), so
+// the sweep of a segment reads whole tiles whatever the segment's offset in the packed rows.
 __global__ __launch_bounds__(256) void quant_vt_kernel(const bf16* __restrict__ v, int64_t v_rs, int S, int heads,
-                                                       int ntiles, const float* __restrict__ scales,
+                                                       const int* __restrict__ cu_seqlens, int nseg, int tps,
+                                                       const float* __restrict__ scales,
                                                        unsigned char* __restrict__ vt8) {
     __shared__ __attribute__((aligned(16))) unsigned char tile[KVBLK][HD + 16];
-    const int t = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int seg = blockIdx.x / tps, t = blockIdx.x % tps, h = blockIdx.y, tid = threadIdx.x;
+    int seg_lo = 0, seg_hi = S;
+    if (cu_seqlens) {
+        seg_lo = cu_seqlens[seg];
+        seg_hi = cu_seqlens[seg + 1];
+    }
+    if (seg_lo + t * KVBLK >= seg_hi) return;          // (uniform) no key of this segment in the tile: never read
     const float* sv = scales + 2 * heads + h * HD;
     for (int item = tid; item < KVBLK * (HD / 8); item += 256) {
         const int key = item / (HD / 8), c = item % (HD / 8);
-        const int row = t * KVBLK + key;
+        const int row = seg_lo + t * KVBLK + key;
         u32x2 o = {0u, 0u};
-        if (row < S) {
+        if (row < seg_hi) {
             const bf16x8 x = *reinterpret_cast<const bf16x8*>(v + (int64_t)row * v_rs + h * HD + c * 8);
             int w = 0;
             w = __builtin_amdgcn_cvt_pk_fp8_f32((float)x[0] / sv[c * 8 + 0], (float)x[1] / sv[c * 8 + 1], w, false);
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(256) void quant_vt_kernel(const bf16* __restrict__ 
         *reinterpret_cast<u32x2*>(&tile[key][c * 8]) = o;
     }
     __syncthreads();
-    unsigned char* out = vt8 + ((int64_t)h * ntiles + t) * TILE_BYTES;
+    unsigned char* out = vt8 + (((int64_t)h * nseg + seg) * tps + t) * TILE_BYTES;
     for (int item = tid; item < HD * (KVBLK / 4); item += 256) {          // 4 slots (one dword) per item
         const int d = item / (KVBLK / 4), p0 = (item % (KVBLK / 4)) * 4;
         unsigned w = 0;
@@ -200,7 +209,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
                                                           const unsigned char* __restrict__ K8,
                                                           const unsigned char* __restrict__ VT8,
                                                           const float* __restrict__ scales, bf16* __restrict__ O,
-                                                          int64_t o_rs, int S, int heads, int nqb, int ntiles,
+                                                          int64_t o_rs, const int* __restrict__ cu_seqlens,
+                                                          int nseg, int tps, int S, int heads, int nqb,
                                                           float scale_log2e, int nwg_full, int split,
                                                           float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -222,9 +232,18 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
         part = si % split;
         nparts = split;
     }
-    const int qb = w % nqb, head = w / nqb;
-    const int q0 = qb * QBLK;
+    // work item = (segment, head, block of 256 query rows of the segment); segment s covers rows cu[s] .. cu[s+1]
+    const int qb = w % nqb, head = (w / nqb) % heads, seg = w / (nqb * heads);
+    int seg_lo = 0, seg_hi = S;
+    if (cu_seqlens) {
+        seg_lo = cu_seqlens[seg];
+        seg_hi = cu_seqlens[seg + 1];
+    }
+    const int q0 = seg_lo + qb * QBLK;
+    if (q0 >= seg_hi) return;                                        // (uniform) no query row of the segment here
     const int C = heads * HD;
+    const int nkv = seg_hi - seg_lo;
+    const int ntiles = min((nkv + KVBLK - 1) / KVBLK, tps);          // (a segment longer than max_seqlen stays in its grid)
     const int t0 = (int)((int64_t)ntiles * part / nparts);           // this block's KV tiles: [t0, t0 + nt)
     const int nt = (int)((int64_t)ntiles * (part + 1) / nparts) - t0;
     float* wsp = ws + (int64_t)((w - nwg_full) * split + part) * WS_FLOATS;
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     // Q fragments: d = 64 ks + 32 hh .. + 32 of query row r
     i32x8 qf[2];
     {
-        const int qrow = min(q0 + wave * 32 + r, S - 1);
+        const int qrow = min(q0 + wave * 32 + r, seg_hi - 1);
         const unsigned char* qp = Q8 + (int64_t)qrow * C + head * HD + hh * 32;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -250,12 +269,12 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     // staging: one 16-B piece of K and one of V^T per thread and tile
     const int skey = tid >> 3, sch = tid & 7;
     const unsigned char* kp_g = K8 + head * HD + sch * 16;
-    const unsigned char* vp_g = VT8 + (int64_t)head * ntiles * TILE_BYTES + tid * 16;
+    const unsigned char* vp_g = VT8 + ((int64_t)head * nseg + seg) * tps * TILE_BYTES + tid * 16;
     const unsigned k_dst = k_off(skey, sch), v_dst = v_off(tid >> 2, tid & 3);
     int kt = 0, vt = 0;                                // next tile to load
     i32x4 kreg, vreg;
     auto load_k = [&]() {
-        const int row = min((t0 + min(kt, nt - 1)) * KVBLK + skey, S - 1);
+        const int row = min(seg_lo + (t0 + min(kt, nt - 1)) * KVBLK + skey, seg_hi - 1);
         kreg = *reinterpret_cast<const i32x4*>(kp_g + (int64_t)row * C);
         ++kt;
     };
@@ -307,8 +326,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
         // ================= vector segment: online softmax of S(t) -> P(t) in e4m3
         load_k();                               // K(t+2)  (clamped repeats past the end)
         load_v();                               // V(t+1)
-        if (t0 + t == ntiles - 1 && (S & (KVBLK - 1))) {
-            const int valid = S - (t0 + t) * KVBLK;
+        if (t0 + t == ntiles - 1 && (nkv & (KVBLK - 1))) {
+            const int valid = nkv - (t0 + t) * KVBLK;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     }
     const float inv = 1.f / l_tot;
     const int qrow = q0 + wave * 32 + r;
-    if (qrow < S) {
+    if (qrow < seg_hi) {
         bf16* op = O + (int64_t)qrow * o_rs + head * HD + 4 * hh;
         const float* sv = scales + 2 * heads + head * HD + 4 * hh;
 #pragma unroll
@@ -432,30 +451,37 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
 
 }  // namespace
 
-// Bytes of the quantised operands for S tokens: q8 + k8 (S*heads*128 each), vt8 (heads * ceil(S/64) * 8192),
-// scales (fp32: 2*heads + 128*heads), the column amax (3*heads*128 fp32) and its per-row-block partials.  Layout
-// inside the buffer, in this order, every part 256-byte aligned.
+// Bytes of the quantised operands: q8 + k8 (S*heads*128 each), vt8 (heads * nseg * ceil(max_seqlen/64) * 8192: every
+// segment has its own tile grid), scales (fp32: 2*heads + 128*heads), the column amax (3*heads*128 fp32) and its
+// per-row-block partials, the partials of a split last round.  Layout inside the buffer, in this order, every part
+// 256-byte aligned.
 static int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
-extern "C" int64_t fp_attn_fp8_workspace_bytes(int total_tokens, int heads) {
-    const int64_t C = (int64_t)heads * HD, nt = (total_tokens + KVBLK - 1) / KVBLK;
+extern "C" int64_t fp_attn_fp8_varlen_workspace_bytes(int total_tokens, int heads, int nseg, int max_seqlen) {
+    const int64_t C = (int64_t)heads * HD, tps = (max_seqlen + KVBLK - 1) / KVBLK;
     const int64_t nblk = (total_tokens + AMAX_ROWS - 1) / AMAX_ROWS;
-    return 2 * align256((int64_t)total_tokens * C) + align256(heads * nt * TILE_BYTES) + align256((2 * heads + C) * 4) +
-           align256(3 * C * 4) + align256(nblk * 3 * C * 4) + align256((int64_t)fpi_attn_cu_count() * WS_FLOATS * 4);
+    return 2 * align256((int64_t)total_tokens * C) + align256(heads * nseg * tps * TILE_BYTES) +
+           align256((2 * heads + C) * 4) + align256(3 * C * 4) + align256(nblk * 3 * C * 4) +
+           align256((int64_t)fpi_attn_cu_count() * WS_FLOATS * 4);
+}
+extern "C" int64_t fp_attn_fp8_workspace_bytes(int total_tokens, int heads) {
+    return fp_attn_fp8_varlen_workspace_bytes(total_tokens, heads, 1, total_tokens);
 }
 
-extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
-                               int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int total_tokens,
-                               int heads, int head_dim, float softmax_scale, void* workspace,
-                               int64_t workspace_bytes, void* stream) {
+extern "C" int fp_attn_fwd_fp8_varlen(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
+                                      int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
+                                      const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens, int heads,
+                                      int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes,
+                                      void* stream) {
     FP_REQUIRE(q && k && v && o && workspace && head_dim == HD && heads > 0 && heads <= 4096 && total_tokens >= 0);
+    FP_REQUIRE(nseg >= 1 && (cu_seqlens || nseg == 1) && max_seqlen >= 0 && max_seqlen <= total_tokens);
     FP_REQUIRE(q_row_stride % 8 == 0 && k_row_stride % 8 == 0 && v_row_stride % 8 == 0 && o_row_stride % 4 == 0);
     FP_REQUIRE(q_row_stride >= (int64_t)heads * HD && k_row_stride >= (int64_t)heads * HD &&
                v_row_stride >= (int64_t)heads * HD && o_row_stride >= (int64_t)heads * HD);
     FP_REQUIRE(((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0 &&
                ((uintptr_t)o & 7) == 0 && ((uintptr_t)workspace & 255) == 0);
-    FP_REQUIRE(workspace_bytes >= fp_attn_fp8_workspace_bytes(total_tokens, heads));
-    if (total_tokens == 0) return 0;
-    const int S = total_tokens, C = heads * HD, nt = (S + KVBLK - 1) / KVBLK;
+    FP_REQUIRE(workspace_bytes >= fp_attn_fp8_varlen_workspace_bytes(total_tokens, heads, nseg, max_seqlen));
+    if (total_tokens == 0 || max_seqlen == 0) return 0;
+    const int S = total_tokens, C = heads * HD, tps = (max_seqlen + KVBLK - 1) / KVBLK;
     hipStream_t st = (hipStream_t)stream;
     unsigned char* p = (unsigned char*)workspace;
     unsigned char* q8 = p;
@@ -463,7 +489,7 @@ extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void
     unsigned char* k8 = p;
     p += align256((int64_t)S * C);
     unsigned char* vt8 = p;
-    p += align256((int64_t)heads * nt * TILE_BYTES);
+    p += align256((int64_t)heads * nseg * tps * TILE_BYTES);
     float* scales = (float*)p;
     p += align256((2 * heads + C) * 4);
     float* amax = (float*)p;
@@ -482,11 +508,12 @@ extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void
     quant_qk_kernel<<<dim3(2048), dim3(256), 0, st>>>((const bf16*)q, (const bf16*)k, q_row_stride, k_row_stride, S, heads,
                                                       scales, q8, k8);
     FP_CHECK_LAUNCH();
-    quant_vt_kernel<<<dim3((unsigned)nt, (unsigned)heads), dim3(256), 0, st>>>((const bf16*)v, v_row_stride, S, heads, nt,
-                                                                             scales, vt8);
+    FP_REQUIRE((int64_t)nseg * tps < (1ll << 31));
+    quant_vt_kernel<<<dim3((unsigned)(nseg * tps), (unsigned)heads), dim3(256), 0, st>>>(
+        (const bf16*)v, v_row_stride, S, heads, cu_seqlens, nseg, tps, scales, vt8);
     FP_CHECK_LAUNCH();
-    const int nqb = (S + QBLK - 1) / QBLK;
-    const int64_t nwg = (int64_t)nqb * heads;
+    const int nqb = (max_seqlen + QBLK - 1) / QBLK;
+    const int64_t nwg = (int64_t)nqb * heads * nseg;
     FP_REQUIRE(nwg < (1ll << 31));
     // one workgroup per CU is resident: when the last round is at most half full its items are cut into KV ranges
     const int ncu = fpi_attn_cu_count();
@@ -498,11 +525,20 @@ extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void
     }
     const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
     auto kern = attn_fp8_kernel<8>;
-    kern<<<dim3((unsigned)grid), dim3(512), 4 * TILE_BYTES, st>>>(q8, k8, vt8, scales, (bf16*)o, o_row_stride, S, heads, nqb,
-                                                                nt, softmax_scale * 1.4426950408889634f, nwg_full, split,
-                                                                tail_ws);
+    kern<<<dim3((unsigned)grid), dim3(512), 4 * TILE_BYTES, st>>>(q8, k8, vt8, scales, (bf16*)o, o_row_stride, cu_seqlens, nseg,
+                                                                tps, S, heads, nqb, softmax_scale * 1.4426950408889634f,
+                                                                nwg_full, split, tail_ws);
     FP_CHECK_LAUNCH();
     if (nwg_full < nwg)
-        return fpi_attn_combine(tail_ws, o, o_row_stride, S, heads, nqb, nwg_full, split, (int)(nwg - nwg_full), st);
+        return fpi_attn_combine(tail_ws, o, o_row_stride, cu_seqlens, S, heads, nqb, nwg_full, split, (int)(nwg - nwg_full), st);
     return 0;
+}
+
+extern "C" int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
+                               int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int total_tokens,
+                               int heads, int head_dim, float softmax_scale, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+    return fp_attn_fwd_fp8_varlen(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, nullptr, 1,
+                                  total_tokens, total_tokens, heads, head_dim, softmax_scale, workspace, workspace_bytes,
+                                  stream);
 }

@@ -1014,10 +1014,11 @@ extern "C" int fp_debug_attn_variant(int v) {
 
 // Library-internal (attn_fp8.hip): the merge of split tail items and the CU count behind the split decision.
 __attribute__((visibility("hidden"))) int fpi_attn_cu_count() { return cu_count(); }
-__attribute__((visibility("hidden"))) int fpi_attn_combine(const float* ws, void* o, int64_t o_rs, int total, int heads,
-                                                           int nqb, int nwg_full, int split, int ntail, hipStream_t st) {
-    attn_combine_kernel<<<dim3((unsigned)(ntail * 16)), dim3(256), 0, st>>>(ws, (bf16*)o, o_rs, nullptr, total, heads, nqb,
-                                                                            nwg_full, split);
+__attribute__((visibility("hidden"))) int fpi_attn_combine(const float* ws, void* o, int64_t o_rs, const int* cu_seqlens,
+                                                           int total, int heads, int nqb, int nwg_full, int split,
+                                                           int ntail, hipStream_t st) {
+    attn_combine_kernel<<<dim3((unsigned)(ntail * 16)), dim3(256), 0, st>>>(ws, (bf16*)o, o_rs, cu_seqlens, total, heads,
+                                                                            nqb, nwg_full, split);
     FP_CHECK_LAUNCH();
     return 0;
 }

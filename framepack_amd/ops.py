@@ -166,10 +166,11 @@ _ATTN_FP8_WS = {}
 
 
 def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, out: Optional[torch.Tensor] = None,
-                  scale: Optional[float] = None) -> torch.Tensor:
-    """K1, fp8 variant (opt-in): one segment, Q / K / P / V in e4m3 on the fp8 MFMA; q, k, v as for `attention`
-    (bf16; quantised inside the call).  A few per cent away from the bf16 kernel.  out may alias q."""
-    _dev(q, k, v, out)
+                  scale: Optional[float] = None, cu_seqlens: Optional[torch.Tensor] = None,
+                  max_seqlen: Optional[int] = None) -> torch.Tensor:
+    """K1, fp8 variant (opt-in): Q / K / P / V in e4m3 on the fp8 MFMA; q, k, v, cu_seqlens, max_seqlen as for
+    `attention` (bf16; quantised inside the call).  A few per cent away from the bf16 kernel.  out may alias q."""
+    _dev(q, k, v, out, cu_seqlens)
     q2, rows, cols, qs = _rows2d(q)
     k2, _, _, ks = _rows2d(k)
     v2, _, _, vs = _rows2d(v)
@@ -179,10 +180,16 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
         out = torch.empty((rows, cols), dtype=BF16, device=q.device)
     o2, orows, ocols, os_ = _rows2d(out)
     assert (orows, ocols) == (rows, cols) and out.dtype == BF16
+    nseg = 1
+    if cu_seqlens is not None:
+        assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_contiguous()
+        nseg = cu_seqlens.numel() - 1
+    if max_seqlen is None:
+        max_seqlen = rows
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
     lib = _lib.load()
-    need = lib.fp_attn_fp8_workspace_bytes(rows, heads)
+    need = lib.fp_attn_fp8_varlen_workspace_bytes(rows, heads, nseg, max_seqlen)
     key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
     ws = _ATTN_FP8_WS.get(key)
     if ws is None or ws.numel() < need:
@@ -191,8 +198,9 @@ def attention_fp8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     if ATTN_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(q.device))
-    _lib.check(lib.fp_attn_fwd_fp8(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o2.data_ptr(), qs, ks, vs, os_, rows,
-                                   heads, 128, scale, ws.data_ptr(), ws.numel(), _stream(q)), "fp_attn_fwd_fp8")
+    _lib.check(lib.fp_attn_fwd_fp8_varlen(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), o2.data_ptr(), qs, ks, vs, os_,
+                                          _ptr(cu_seqlens), nseg, max_seqlen, rows, heads, 128, scale, ws.data_ptr(),
+                                          ws.numel(), _stream(q)), "fp_attn_fwd_fp8_varlen")
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(q.device))
         ATTN_EVENTS.append((ev[0], ev[1], rows, heads))

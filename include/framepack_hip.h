@@ -58,16 +58,23 @@ int fp_attn_fwd_bf16_static(const void* q, const void* k, const void* v, void* o
                             const int* cu_seqlens, int nseg, int max_seqlen, int total_tokens,
                             int heads, int head_dim, float softmax_scale, void* stream);
 
-/* K1, fp8 variant (opt-in; the role of the reference's quantised SageAttention branch, hunyuan_video_packed.py:92-94):
- * the same attention for ONE segment [0, total_tokens) with Q, K, P and V in e4m3 on the fp8 MFMA.  The call
- * quantises q, k, v (bf16, same strides as above) into `workspace` first - one scale per head for q and for k, one
- * per (head, channel) for v, V stored transposed in the kernel's key order - and then runs the sweep.  The result
- * differs from fp_attn_fwd_bf16's by a few per cent (3 mantissa bits).  workspace: device memory, 256-byte aligned,
- * at least fp_attn_fp8_workspace_bytes(total_tokens, heads) bytes; o may alias q. */
+/* K1, fp8 variant (opt-in; the role of the reference's quantised SageAttention branches, hunyuan_video_packed.py:92-94
+ * `sageattn` and :106-107 `sageattn_varlen`): the same attention with Q, K, P and V in e4m3 on the fp8 MFMA, for one
+ * segment or for the varlen segments of cu_seqlens (same meaning as in fp_attn_fwd_bf16).  The call quantises q, k, v
+ * (bf16, same strides as above) into `workspace` first - one scale per head for q and for k, one per (head, channel) for
+ * v, taken over ALL rows; V stored transposed in the kernel's key order, every segment with its own grid of 64-key
+ * tiles - and then runs the sweep.  The result differs from fp_attn_fwd_bf16's by a few per cent (3 mantissa bits).
+ * workspace: device memory, 256-byte aligned, at least fp_attn_fp8_varlen_workspace_bytes(total_tokens, heads, nseg,
+ * max_seqlen) bytes (fp_attn_fp8_workspace_bytes(total_tokens, heads) for the one-segment call); o may alias q. */
 int64_t fp_attn_fp8_workspace_bytes(int total_tokens, int heads);
 int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
                     int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int total_tokens, int heads,
                     int head_dim, float softmax_scale, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t fp_attn_fp8_varlen_workspace_bytes(int total_tokens, int heads, int nseg, int max_seqlen);
+int fp_attn_fwd_fp8_varlen(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
+                           int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, const int* cu_seqlens,
+                           int nseg, int max_seqlen, int total_tokens, int heads, int head_dim, float softmax_scale,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /* K2  in-place RMSNorm over head_dim (=128) of q and k, then RoPE on token rows [0, rope_rows).
  * Replaces diffusers_helper/dit_common.py:31-39 (RMSNorm_forward) + hunyuan_video_packed.py:80-86

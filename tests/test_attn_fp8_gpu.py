@@ -108,6 +108,47 @@ def test_fp8_attention_split_last_round_matches_unsplit_sweeps():
         assert rel_l2(got[lo:hi, sl], p @ dv[:, sl].double()) < 3e-2, (h, lo)
 
 
+@pytest.mark.parametrize("cuts", [(0, 300, 517, 517, 1000, 1064), (0, 1, 2, 258), (0, 0, 700), (0, 2174)])
+def test_fp8_attention_over_cu_seqlens_segments(cuts):
+    """Segments attend only within themselves (the packed batch of ref: models/hunyuan_video_packed.py:110-122); the
+    quantiser's scales are taken over ALL rows, so every segment is compared with fp64 attention of its own rows of the
+    operands dequantised with the global scales.  Covers an empty segment, one-row segments, a leading empty segment,
+    ragged last query blocks and KV tiles inside the buffer, and the one-segment call being the plain entry point."""
+    heads = 2
+    S = cuts[-1]
+    q, k, v = rand_qkv(S, heads, seed=S + len(cuts))
+    cu = torch.tensor(cuts, dtype=torch.int32, device=DEV)
+    max_len = max(b - a for a, b in zip(cuts[:-1], cuts[1:]))
+    sentinel = torch.full((S, heads * 128), 7.0, dtype=BF, device=DEV)
+    got = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads, out=sentinel, cu_seqlens=cu, max_seqlen=max_len)
+    assert torch.isfinite(got.float()).all()
+    dq, dk, dv = dequantised(q, k, v, heads)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            ref = attn64(dq[a:b], dk[a:b], dv[a:b], heads)
+            assert rel_l2(got[a:b], ref) < 3e-2, (a, b, rel_l2(got[a:b], ref))
+    if len(cuts) == 2:
+        assert torch.equal(got, ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads))
+
+
+def test_fp8_attention_segments_in_a_split_last_round():
+    """Two segments whose work items do not divide by the CU count: the last round is swept as KV ranges of ITS OWN
+    segment and merged with the segment-aware combine."""
+    heads = 3
+    cuts = (0, 43 * 256 + 10, 87 * 256 - 5)
+    S = cuts[-1]
+    q, k, v = rand_qkv(S, heads, seed=77)
+    cu = torch.tensor(cuts, dtype=torch.int32, device=DEV)
+    got = ops.attention_fp8(q.to(DEV), k.to(DEV), v.to(DEV), heads, cu_seqlens=cu, max_seqlen=cuts[2] - cuts[1])
+    assert torch.isfinite(got.float()).all()
+    dq, dk, dv = dequantised(q, k, v, heads)
+    for h, lo, hi, a, b in ((2, cuts[1] - 30, cuts[1], 0, cuts[1]), (2, S - 30, S, cuts[1], S), (0, 100, 130, 0, cuts[1]),
+                            (1, cuts[1], cuts[1] + 30, cuts[1], S), (2, cuts[1] + 40 * 256, cuts[1] + 40 * 256 + 30, cuts[1], S)):
+        sl = slice(h * 128, (h + 1) * 128)
+        p = torch.softmax(dq[lo:hi, sl].double() @ dk[a:b, sl].double().T / math.sqrt(128.0), dim=-1)
+        assert rel_l2(got[lo:hi, sl], p @ dv[a:b, sl].double()) < 3e-2, (h, lo)
+
+
 def test_fp8_attention_rejects_bad_arguments():
     q = torch.zeros(8, 128, dtype=BF, device=DEV)
     with pytest.raises(AssertionError):
