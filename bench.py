@@ -11,8 +11,9 @@ random-init bf16 weights and synthetic inputs resident in HBM.  W warm-up steps,
 bracketed by barrier + torch.cuda.synchronize(); the reported time is the max over ranks.
 value = seconds per 25-step section = 25 * (timed seconds / K).
 
-N > 1: Ulysses sequence parallelism (image tokens sharded, one RCCL all-to-all pair per attention); the whole
-section is ONE job spread over N GPUs, so scaling is "strong".
+N > 1: Ulysses sequence parallelism (image tokens sharded; per attention the heads go through RCCL all-to-alls in
+chunks, a chunk's exchange running under the other chunk's attention where that keeps the chip full -
+framepack_amd/ulysses.py); the whole section is ONE job spread over N GPUs, so scaling is "strong".
 
 Also printed on the same JSON line:
   roofline     - the dominant kernel (K1 flash attention): algorithmic FLOPs per launch (4 * S^2 * heads * 128,
@@ -178,10 +179,12 @@ def main():
         fence()
         ops.ATTN_EVENTS = []
         t0 = time.perf_counter()
-        run_steps(args.steps)
+        out = run_steps(args.steps)
         fence()
         elapsed = time.perf_counter() - t0
         events, ops.ATTN_EVENTS = ops.ATTN_EVENTS, None
+        if not bool(torch.isfinite(out).all()):
+            raise SystemExit("bench: the timed steps produced non-finite latents - the number would be meaningless")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -189,8 +192,9 @@ def main():
     elapsed = t.item()
 
     # dominant kernel, measured live on its own stream
-    att_ms = [a.elapsed_time(b) for a, b, _, _ in events]
-    rows, heads = events[0][2], events[0][3]
+    # (the token refiner's two small launches per step go through the same op: the block launches are the largest)
+    rows, heads = max((e[2], e[3]) for e in events)
+    att_ms = [a.elapsed_time(b) for a, b, r, h in events if (r, h) == (rows, heads)]
     att_avg_s = sum(att_ms) / len(att_ms) / 1e3
     flops_per_launch = 4.0 * rows * rows * heads * 128
     achieved = flops_per_launch / att_avg_s
@@ -205,7 +209,7 @@ def main():
     if args.fp8:
         traffic = None                                      # the PMC passes were made on the bf16 kernel
     roofline = {"kernel": "attn_fp8_kernel<8> + its quantisation kernels (K1 fp8 variant, MFMA 32x32x64 f8f6f4)" if args.fp8
-                else "attn_v3_kernel<8> (K1 flash attention, bf16 MFMA 32x32x16, one wave per SIMD, S^T - m accumulated in VGPRs)", "bound": "mfma",
+                else "attn_v3_kernel<60> (K1 flash attention, bf16 MFMA 32x32x16, one wave per SIMD, S^T - m accumulated in VGPRs)", "bound": "mfma",
                 "achieved": round(achieved / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (PMC, profiles/r1_g_attn_hbm_traffic.json; algorithmic 476 MB)",

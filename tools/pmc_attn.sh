@@ -3,6 +3,7 @@
 set -e
 V=$1; OUT=$2; mkdir -p $OUT
 export REPEAT=1
+export ATTN_VARIANT=$V
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --output-format csv -d $R/$OUT/p1 -- python3 $R/tools/bench_attn.py 19385 24 3
