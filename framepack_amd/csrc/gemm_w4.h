@@ -374,6 +374,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         }
     };
     auto epilogue = [&](int em0, int en0, int ecw) __attribute__((always_inline)) {
+      if constexpr (sizeof(TO) == 4) {
+        // fp32 output (the VAE mid-block attention's logits; EPI 0, no bias): straight from the accumulators, 16 B per
+        // lane - a row tile's store covers 16 rows x 64 B per instruction.  N % 4 == 0.
+        const int el = opaque_lane();
+        const int fr = el & 15, fq = el >> 4;
+        const int nb = en0 + wc * ecw + 4 * fq;
+        static_for<8>([&](auto MI_) __attribute__((always_inline)) {
+            constexpr int mi = MI_;
+            const int mrow0 = em0 + wr * 128 + mi * 16;
+            if (mrow0 >= M) return;                            // wave-uniform
+            static_for<8>([&](auto NI_) __attribute__((always_inline)) {
+                constexpr int ni = NI_;
+                if constexpr (ni >= NT) return;
+                const int n = nb + ni * 16;
+                const f32x4 av = acc_read<(mi * 8 + ni) * 4>();
+                if (mrow0 + fr < M && n < N) *reinterpret_cast<f32x4*>(C + (int64_t)(mrow0 + fr) * ldc + n) = av;
+            });
+        });
+      } else {
         unsigned stage_off = 2 * BUF_BYTES + wave * 8192;      // opaque, so that the 4096 of the second stage buffer
         asm volatile("" : "+v"(stage_off));                    // stays an instruction immediate, not 12 more addresses
         unsigned char* stage = smem + stage_off;
@@ -443,6 +462,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                 if (col_ok && mrow0 + row < M) *reinterpret_cast<Tx8*>(C + (int64_t)(mrow0 + row) * ldc + gcol) = ov;
             }
         });
+      }
     };
 
     static_assert(KS == 2 || (KS == 1 && NT == 8), "16-bit MFMA 16x16x32 (two K steps per tile) or fp8 16x16x128 (one)");

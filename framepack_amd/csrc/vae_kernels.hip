@@ -8,7 +8,8 @@
 //     MFMA pipeline of gemm_pipeline.h (the A operand is gathered by LDS-DMA, one tap per K tile);
 //   * 1x1x1 convolutions and the mid-block attention's linears / QK^T / PV                -> dense fp16 GEMM;
 //   * GroupNorm(32) (+SiLU): deterministic two-stage statistics, then one fused normalise+affine+SiLU pass;
-//   * the mid-block attention's frame-causal softmax over materialised scores (one head of 512 channels).
+//   * the mid-block attention (one head of 512 channels): fp32 logits of a chunk of query rows (the dense GEMM with
+//     an fp32 epilogue), frame-causal softmax into fp16 in place, P.V - the S x S matrix is never materialised.
 #include "gemm_w4.h"
 
 typedef _Float16 f16;
@@ -38,6 +39,21 @@ extern "C" int fp_gemm_f16(const void* a, int64_t lda, const void* a2, int k1, c
                         : launch<f16, 4, 0>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, resid, ldr, gate, cg, st);
         default: return (int)hipErrorInvalidValue;      // the VAE uses bias-only and bias+residual
     }
+}
+
+// c [M, N] fp32 = a [M, K] . w [N, K]^T, fp16 operands, no bias: the mid-block attention's logits (kept in fp32: one
+// head of 512 channels, and an fp16 logit carries an absolute error of |s| 2^-11 into the exponent).
+extern "C" int fp_gemm_f16_f32out(const void* a, int64_t lda, const void* w, int64_t ldw, void* c, int64_t ldc, int M,
+                                  int N, int K, void* stream) {
+    using namespace fp_gemm;
+    FP_REQUIRE(a && w && c && M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0);
+    FP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && lda >= K && ldw >= K && ldc >= N);
+    FP_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 15) == 0);
+    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN) < (1ll << 31));
+    if (M == 0) return 0;
+    const ConvGeom cg{};
+    return launch_w4<f16, 0, 0, float>(a, lda, 0, K, w, ldw, nullptr, c, ldc, M, N, K, 0, nullptr, 0, nullptr, cg,
+                                       (hipStream_t)stream);
 }
 
 static int conv_launch(const void* x, const void* w, const void* bias, void* y, const fp_gemm::ConvGeom& cg, int Cout,
@@ -184,30 +200,34 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     }
 }
 
-// In-place softmax of row i over columns [0, (i / tokens_per_frame + 1) * tokens_per_frame) of scale * s;
-// the other columns up to `cols` are written as 0.  One workgroup per row; two passes over the row.
-__global__ __launch_bounds__(256) void softmax_framecausal_kernel(f16* __restrict__ s, int64_t ld, int cols,
-                                                                  int tokens_per_frame, float scale_log2e) {
+// Frame-causal softmax of fp32 logits, the fp16 probabilities written IN PLACE over the front half of each row
+// (row i: floats s[i * ld ..], halves ((f16*)(s + i * ld))[0 .. cols)).  Row i (query row0 + i) keeps the columns below
+// valid = min(((row0 + i) / q_per_frame + 1) * k_per_frame, cols); the columns [valid, cols) become 0.
+// One workgroup per row.  Pass 1: max and sum.  Pass 2, in chunks of 2048 columns: all threads read their 8 floats,
+// barrier, write their 8 halves - the halves of a chunk land on floats of this or an earlier chunk, all read by then.
+__global__ __launch_bounds__(256) void softmax_f32_to_f16_kernel(float* __restrict__ s, int64_t ld, int cols, int row0,
+                                                                 int q_per_frame, int k_per_frame, float scale_log2e) {
     __shared__ float red[8];
     const int row = blockIdx.x;
-    f16* p = s + (int64_t)row * ld;
-    const int valid = min((row / tokens_per_frame + 1) * tokens_per_frame, cols);
+    float* p = s + (int64_t)row * ld;
+    f16* ph = reinterpret_cast<f16*>(p);
+    const int64_t lim = ((int64_t)(row0 + row) / q_per_frame + 1) * k_per_frame;
+    const int valid = (int)(lim < cols ? lim : cols);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float m = -INFINITY, l = 0.f;
     for (int c = threadIdx.x * 8; c < valid; c += 256 * 8) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(p + c);
-        float mx = (float)v[0];                                        // column c < valid
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
+        float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+        float mx = v[0];                                               // column c < valid
 #pragma unroll
-        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, c + j < valid ? (float)v[j] : -INFINITY);
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, c + j < valid ? v[j] : -INFINITY);
         const float mn = fmaxf(m, mx * scale_log2e);
         float acc = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            acc += c + j < valid ? __builtin_amdgcn_exp2f((float)v[j] * scale_log2e - mn) : 0.f;
+        for (int j = 0; j < 8; ++j) acc += c + j < valid ? __builtin_amdgcn_exp2f(v[j] * scale_log2e - mn) : 0.f;
         l = l * __builtin_amdgcn_exp2f(m - mn) + acc;
         m = mn;
     }
-    // combine (m, l) over the workgroup
     float mw = m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o, 64));
@@ -220,18 +240,25 @@ __global__ __launch_bounds__(256) void softmax_framecausal_kernel(f16* __restric
     if (lane == 0) red[4 + wave] = lw;
     __syncthreads();
     const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
-    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) {
+    for (int base = 0; base < valid; base += 256 * 8) {               // (uniform trip count)
+        const int c = base + threadIdx.x * 8;
         f16x8 o;
         if (c < valid) {
-            const f16x8 v = *reinterpret_cast<const f16x8*>(p + c);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + c), b = *reinterpret_cast<const f32x4*>(p + c + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                o[j] = c + j < valid ? (f16)(__builtin_amdgcn_exp2f((float)v[j] * scale_log2e - mt) * inv) : (f16)0.f;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+                o[j] = c + j < valid ? (f16)(__builtin_amdgcn_exp2f(v[j] * scale_log2e - mt) * inv) : (f16)0.f;
         }
-        *reinterpret_cast<f16x8*>(p + c) = o;
+        __syncthreads();
+        if (c < valid) *reinterpret_cast<f16x8*>(ph + c) = o;
+    }
+    __syncthreads();                                                   // every logit has been read: the zero tail may land
+    for (int c = (valid + 7) / 8 * 8 + threadIdx.x * 8; c < cols; c += 256 * 8) {
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+        *reinterpret_cast<f16x8*>(ph + c) = o;
     }
 }
 
@@ -274,15 +301,16 @@ extern "C" int fp_groupnorm_apply_f16(const void* x, void* y, int64_t rows, int 
     return 0;
 }
 
-// In-place frame-causal softmax of the mid-block attention scores s [rows, cols] (row stride ld): token i may
-// attend to the tokens of frames <= its own (prepare_causal_attention_mask of the diffusers VAE).
-extern "C" int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int tokens_per_frame, float scale,
-                                          void* stream) {
-    FP_REQUIRE(s && rows >= 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 8 == 0 && tokens_per_frame > 0);
-    FP_REQUIRE(((uintptr_t)s & 15) == 0);
+// Frame-causal softmax of the mid-block attention's fp32 logits s [rows, cols] (row stride ld floats); the fp16
+// probabilities overwrite the front of each row: P = (f16*)s viewed [rows, cols] with row stride 2 ld halves.
+// Query i of the call is token row0 + i; it attends to the keys below ((row0 + i) / q_per_frame + 1) * k_per_frame.
+extern "C" int fp_softmax_framecausal_f32_f16(void* s, int rows, int cols, int64_t ld, int row0, int q_per_frame,
+                                              int k_per_frame, float scale, void* stream) {
+    FP_REQUIRE(s && rows >= 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 4 == 0 && row0 >= 0);
+    FP_REQUIRE(q_per_frame > 0 && k_per_frame > 0 && ((uintptr_t)s & 15) == 0);
     if (rows == 0) return 0;
-    softmax_framecausal_kernel<<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>(
-        (f16*)s, ld, cols, tokens_per_frame, scale * 1.4426950408889634f);
+    softmax_f32_to_f16_kernel<<<dim3(rows), dim3(256), 0, (hipStream_t)stream>>>((float*)s, ld, cols, row0, q_per_frame,
+                                                                                 k_per_frame, scale * 1.4426950408889634f);
     FP_CHECK_LAUNCH();
     return 0;
 }

@@ -43,7 +43,8 @@ SIGNATURES = {
     "fp_groupnorm_workspace_floats": [I],
     "fp_groupnorm_stats_f16": [P, L, I, I, F, P, P, P],
     "fp_groupnorm_apply_f16": [P, P, L, I, I, P, P, P, I, P],
-    "fp_softmax_framecausal_f16": [P, I, I, L, I, F, P],
+    "fp_gemm_f16_f32out": [P, L, P, L, P, L, I, I, I, P],
+    "fp_softmax_framecausal_f32_f16": [P, I, I, L, I, I, I, F, P],
 }
 
 _lib = None

@@ -452,11 +452,64 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: 
     return groupnorm_apply(x, groupnorm_stats(x, groups, eps), gamma, beta, groups, silu, out)
 
 
-def softmax_framecausal_(scores: torch.Tensor, tokens_per_frame: int, scale: float) -> torch.Tensor:
-    """In-place frame-causal softmax of scores [rows, cols] fp16 (row stride = cols)."""
+_VAE_ATTN_WS = {}
+VAE_ATTN_WS_BYTES = 512 << 20          # fp32 logits of one query chunk (the whole S x S matrix is never materialised)
+
+
+def gemm_f16_f32out(a: torch.Tensor, weight: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out [M,N] fp32 = a [M,K] @ weight [N,K].T, fp16 operands (row-strided ok), no bias."""
+    _dev(a, weight, out)
+    a_, M, K, lda = _rows2d(a)
+    w_, N, Kw, ldw = _rows2d(weight)
+    o_, Mo, No, ldc = _rows2d(out)
+    assert K == Kw and (Mo, No) == (M, N) and a.dtype == F16 and weight.dtype == F16 and out.dtype == torch.float32
+    _lib.check(_lib.load().fp_gemm_f16_f32out(a_.data_ptr(), lda, w_.data_ptr(), ldw, o_.data_ptr(), ldc, M, N, K,
+                                              _stream(a)), "fp_gemm_f16_f32out")
+    return out
+
+
+def softmax_framecausal_f32_(scores: torch.Tensor, row0: int, q_per_frame: int, k_per_frame: int,
+                             scale: float) -> torch.Tensor:
+    """Frame-causal softmax of fp32 logits [rows, cols] (contiguous); returns the fp16 probabilities, written over the
+    front of each row: a view [rows, cols] with row stride 2 * cols.  Query i is token row0 + i and keeps the keys
+    below ((row0 + i) // q_per_frame + 1) * k_per_frame; the other columns become 0."""
     _dev(scores)
-    assert scores.dim() == 2 and scores.is_contiguous() and scores.dtype == F16
-    _lib.check(_lib.load().fp_softmax_framecausal_f16(scores.data_ptr(), scores.shape[0], scores.shape[1],
-                                                      scores.stride(0), tokens_per_frame, scale, _stream(scores)),
-               "fp_softmax_framecausal_f16")
-    return scores
+    assert scores.dim() == 2 and scores.is_contiguous() and scores.dtype == torch.float32
+    rows, cols = scores.shape
+    _lib.check(_lib.load().fp_softmax_framecausal_f32_f16(scores.data_ptr(), rows, cols, cols, row0, q_per_frame,
+                                                          k_per_frame, scale, _stream(scores)),
+               "fp_softmax_framecausal_f32_f16")
+    return scores.view(F16)[:, :cols]
+
+
+def attention_framecausal(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, q_per_frame: int, k_per_frame: int,
+                          out: Optional[torch.Tensor] = None, scale: float = 1.0) -> torch.Tensor:
+    """The VAE mid-block's attention (one head of C channels) under the frame-causal mask: query token i (frame
+    i // q_per_frame) attends to the keys below (frame + 1) * k_per_frame.
+      q [Sq, C], k [>= Sk rounded up to 64 rows, C] (row-strided ok), vt [C, >= Sk rounded up to 64] = V transposed with
+      FINITE padding columns, all fp16; Sq = T * q_per_frame, Sk = T * k_per_frame.
+    Per frame and chunk of query rows: fp32 logits (fp_gemm_f16_f32out) against the keys the frame may see only, softmax
+    into fp16 in place, P.V - the logits buffer is VAE_ATTN_WS_BYTES at most, cached per (device, stream)."""
+    _dev(q, k, vt, out)
+    Sq, C = q.shape
+    T = Sq // q_per_frame
+    assert Sq == T * q_per_frame and q.dtype == F16 and k.dtype == F16 and vt.dtype == F16
+    n_max = (T * k_per_frame + 63) // 64 * 64
+    assert k.shape[0] >= n_max and k.shape[1] == C and vt.shape[0] == C and vt.shape[1] >= n_max
+    if out is None:
+        out = torch.empty((Sq, C), dtype=F16, device=q.device)
+    key = (q.device, torch.cuda.current_stream(q.device).cuda_stream)
+    ws = _VAE_ATTN_WS.get(key)
+    need = min(Sq * n_max, max(VAE_ATTN_WS_BYTES // 4, 256 * n_max))
+    if ws is None or ws.numel() < need:
+        ws = _VAE_ATTN_WS[key] = torch.empty((need,), dtype=torch.float32, device=q.device)
+    for f in range(T):
+        n = ((f + 1) * k_per_frame + 63) // 64 * 64
+        rows_max = max(256, ws.numel() // n // 256 * 256)
+        for r0 in range(f * q_per_frame, (f + 1) * q_per_frame, rows_max):
+            r1 = min(r0 + rows_max, (f + 1) * q_per_frame)
+            logits = ws[:(r1 - r0) * n].view(r1 - r0, n)
+            gemm_f16_f32out(q[r0:r1], k[:n], logits)
+            p = softmax_framecausal_f32_(logits, r0, q_per_frame, k_per_frame, scale)
+            gemm(p, vt[:, :n], None, out=out[r0:r1])
+    return out

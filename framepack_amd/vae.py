@@ -8,8 +8,9 @@ decoder half loads unchanged), `.config.scaling_factor`, `.dtype/.device` and `d
 decoder on the gfx950 kernels of csrc/vae_kernels.hip: volumes are fp16 channels-last [T, H, W, C], every 3x3x3
 convolution is an implicit GEMM, nearest upsampling is folded into the following convolution's gather,
 GroupNorm+SiLU is one fused pass after a deterministic statistics pass, the resnet skip is added in the
-convolution's epilogue, and the mid-block attention (one head of 512 channels, frame-causal) runs as
-GEMM -> masked softmax -> GEMM on materialised scores (288 GB of HBM make that the simple choice).
+convolution's epilogue, and the mid-block attention (one head of 512 channels, frame-causal) runs per frame and
+chunk of query rows as fp32-logit GEMM (against the keys that frame may see) -> softmax into fp16 in place -> P.V GEMM
+(ops.attention_framecausal): fp32 logits, and at most 512 MB of them at a time whatever the window's size.
 
 The encode half (ref: diffusers_helper/hunyuan.py:107-110 `vae_encode`, run on single images: worker.py:246-272)
 uses the same kernels: the downsamplers are the same implicit GEMM with a stride of 2 in its gather
@@ -409,12 +410,8 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         hn = ops.groupnorm(h, W[name + ".gn.g"], W[name + ".gn.b"], self.config.norm_num_groups, silu=False).reshape(S, C)
         qkv = torch.zeros(Sp, 3 * C, dtype=F16, device=h.device)              # rows >= S stay zero
         ops.gemm(hn, W[name + ".qkv.w"], W[name + ".qkv.b"], out=qkv[:S])
-        scores = torch.empty(S, Sp, dtype=F16, device=h.device)
-        ops.gemm(qkv[:S, :C], qkv[:, C:2 * C], None, out=scores)              # q (pre-scaled) . k^T
-        ops.softmax_framecausal_(scores, H * Wd, 1.0)
         vt = qkv[:, 2 * C:].t().contiguous()                                   # [C, Sp]; padding columns are zero
-        o = ops.gemm(scores, vt, None)
-        del scores
+        o = ops.attention_framecausal(qkv[:S, :C], qkv[:, C:2 * C], vt, H * Wd, H * Wd)   # q is pre-scaled (_prepare)
         out = ops.gemm(o, W[name + ".o.w"], W[name + ".o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
         return out.reshape(T, H, Wd, C)
 
@@ -463,12 +460,8 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         k_all[:S] = kv[:, :C]
         vt = torch.zeros(C, Sp, dtype=F16, device=h.device)
         vt[:, :S] = kv[:, C:].t()
-        scores = torch.empty(Sl, Sp, dtype=F16, device=h.device)
-        ops.gemm(qkv[:, :C], k_all, None, out=scores)                         # q (pre-scaled) . k^T
-        for t in range(T):       # rows of frame t see the first (t + 1) H W keys; the kernel zeroes the other columns
-            ops.softmax_framecausal_(scores[t * Hb * Wd:(t + 1) * Hb * Wd], (t + 1) * H * Wd, 1.0)
-        o = ops.gemm(scores, vt, None)
-        del scores
+        # rows of local frame t see the first (t + 1) H W keys
+        o = ops.attention_framecausal(qkv[:, :C], k_all, vt, Hb * Wd, H * Wd)
         out = ops.gemm(o, W[name + ".o.w"], W[name + ".o.b"], epilogue=ops.EPI_RESIDUAL, resid=x)
         return out.reshape(T, Hb, Wd, C)
 

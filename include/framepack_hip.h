@@ -178,11 +178,22 @@ int fp_groupnorm_stats_f16(const void* x, int64_t rows, int C, int groups, float
 int fp_groupnorm_apply_f16(const void* x, void* y, int64_t rows, int C, int groups, const float* stats,
                            const void* gamma, const void* beta, int silu, void* stream);
 
-/* In-place softmax(scale * s) of the mid-block attention scores s [rows, cols] (row stride ld) under the
- * frame-causal mask of the VAE (token i sees the tokens of frames <= its own; tokens_per_frame = h*w);
- * masked and padding columns are written as 0. */
-int fp_softmax_framecausal_f16(void* s, int rows, int cols, int64_t ld, int tokens_per_frame, float scale,
-                               void* stream);
+/* The mid-block attention (one head of 512 channels, HunyuanVideoMidBlock3D's Attention under
+ * prepare_causal_attention_mask of diffusers 0.33.1) never materialises its S x S matrix: per frame and chunk of query
+ * rows the host side computes fp32 logits against the keys that frame may see, the softmax below, and P.V (fp_gemm_f16).
+ *
+ * c [M, N] fp32 = a [M, K] . w [N, K]^T with fp16 operands and no bias (the logits; K % 64 == 0, N % 8 == 0,
+ * lda, ldw % 8 == 0, ldc % 4 == 0, c 16-byte aligned). */
+int fp_gemm_f16_f32out(const void* a, int64_t lda, const void* w, int64_t ldw, void* c, int64_t ldc, int M, int N,
+                       int K, void* stream);
+
+/* softmax(scale * s) of the fp32 logits s [rows, cols] (row stride ld floats, ld % 4 == 0, cols % 8 == 0) under the
+ * frame-causal mask: query i of the call is token row0 + i and keeps the keys below
+ * ((row0 + i) / q_per_frame + 1) * k_per_frame (q_per_frame = k_per_frame = h*w on one GPU; a band of rows per GPU has
+ * fewer queries per frame than keys).  The fp16 probabilities are written IN PLACE over the front of each row:
+ * P = (f16*)s, [rows, cols] with row stride 2*ld halves; masked and padding columns are written as 0. */
+int fp_softmax_framecausal_f32_f16(void* s, int rows, int cols, int64_t ld, int row0, int q_per_frame,
+                                   int k_per_frame, float scale, void* stream);
 
 /* ---- diagnostics (no counterpart in the reference) --------------------------------------------------------
  * Select the kernel generation used by fp_gemm_bf16 / fp_attn_fwd_bf16 for same-process A/B measurements

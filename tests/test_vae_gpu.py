@@ -116,15 +116,68 @@ def test_groupnorm_silu(rows_shape, C, groups, silu):
     assert torch.equal(got, got2)                                   # two-stage statistics are deterministic
 
 
-def test_softmax_framecausal_matches_masked_softmax():
-    T, hw, pad = 3, 24, 8
-    S = T * hw
-    s = rand(S, S + pad, seed=8, scale=3.0)
-    mask = VO.frame_causal_mask(T, hw, torch.float32)
-    ref = torch.softmax(s[:, :S].float() * 0.37 + mask, dim=-1)
-    got = ops.softmax_framecausal_(s.to(DEV).clone(), hw, 0.37)
-    assert rel_l2(got[:, :S], ref) < 2e-3
-    assert got[:, S:].abs().max().item() == 0 and got[:hw, hw:].abs().max().item() == 0
+def test_gemm_f16_with_fp32_output():
+    a, w = rand(300, 192, seed=40, scale=2.0), rand(328, 192, seed=41, scale=2.0)
+    ref = a.double() @ w.double().T
+    buf = torch.full((300, 336), 7.0, dtype=torch.float32, device=DEV)            # row-strided output, sentinel beyond N
+    qkv = torch.cat([a, rand(300, 64, seed=42)], dim=1).to(DEV)                    # row-strided A
+    got = ops.gemm_f16_f32out(qkv[:, :192], w.to(DEV), buf[:, :328])
+    assert got.dtype == torch.float32 and rel_l2(got, ref) < 1e-6                  # fp16 products are exact in fp32
+    assert (buf[:, 328:] == 7.0).all()
+
+
+@pytest.mark.parametrize("T,qpf,kpf", [(3, 24, 24), (2, 10, 35), (1, 300, 300), (4, 7, 7)])
+def test_softmax_fp32_logits_to_fp16_in_place(T, qpf, kpf):
+    rows, sk = T * qpf, T * kpf
+    cols = (sk + 63) // 64 * 64
+    g = torch.Generator().manual_seed(T * 100 + qpf)
+    s = torch.randn(rows, cols, generator=g) * 30.0                               # logits far beyond fp16's useful precision
+    valid = (torch.arange(rows) // qpf + 1) * kpf
+    mask = torch.arange(cols)[None, :] < valid[:, None]
+    ref = torch.softmax((s.double() * 0.37).masked_fill(~mask, float("-inf")), dim=-1)
+    row0 = 0
+    p = ops.softmax_framecausal_f32_(s.to(DEV), row0, qpf, kpf, 0.37)
+    assert p.dtype == torch.float16 and tuple(p.shape) == (rows, cols) and p.stride(0) == 2 * cols
+    assert rel_l2(p, ref) < 1e-3
+    assert (p.cpu()[~mask] == 0).all()
+    # a chunk that starts inside the sequence (row0 > 0) sees the limits of its own tokens
+    r0 = qpf * (T - 1) + qpf // 2
+    p2 = ops.softmax_framecausal_f32_(s[r0:].contiguous().to(DEV), r0, qpf, kpf, 0.37)
+    assert rel_l2(p2, ref[r0:]) < 1e-3
+
+
+def test_long_rows_of_the_in_place_softmax():
+    """Rows longer than one 2048-column chunk: the fp16 row overwrites fp32 logits that were read chunks earlier."""
+    rows, cols = 5, 3 * 2048 + 448
+    g = torch.Generator().manual_seed(3)
+    s = torch.randn(rows, cols, generator=g) * 4.0
+    for valid in (cols, cols - 13, 2048, 2049, 700):
+        ref = torch.softmax(s[:, :valid].double(), dim=-1)
+        p = ops.softmax_framecausal_f32_(s.to(DEV), 0, rows, valid, 1.0)
+        assert rel_l2(p[:, :valid], ref) < 1e-3, valid
+        assert p[:, valid:].abs().max().item() == 0 if valid < cols else True
+
+
+@pytest.mark.parametrize("T,qpf,kpf,C", [(3, 40, 40, 128), (2, 24, 72, 64), (1, 500, 500, 512)])
+def test_attention_framecausal_matches_masked_attention(T, qpf, kpf, C, monkeypatch):
+    sq, sk = T * qpf, T * kpf
+    sp = (sk + 63) // 64 * 64
+    q, k, v = rand(sq, C, seed=50, scale=1.5), rand(sp, C, seed=51, scale=1.5), rand(sp, C, seed=52)
+    k[sk:] = 0
+    v[sk:] = 0
+    valid = (torch.arange(sq) // qpf + 1) * kpf
+    mask = torch.arange(sk)[None, :] < valid[:, None]
+    s = (q.double() @ k[:sk].double().T * 0.2).masked_fill(~mask, float("-inf"))
+    ref = torch.softmax(s, dim=-1) @ v[:sk].double()
+    vt = v.t().contiguous().to(DEV)
+    got = ops.attention_framecausal(q.to(DEV), k.to(DEV), vt, qpf, kpf, scale=0.2)
+    assert rel_l2(got, ref) < 2e-3
+    # the same through small chunks of query rows (a logits buffer far smaller than the problem)
+    monkeypatch.setattr(ops, "VAE_ATTN_WS_BYTES", 4096)
+    ops._VAE_ATTN_WS.clear()
+    again = ops.attention_framecausal(q.to(DEV), k.to(DEV), vt, qpf, kpf, scale=0.2)
+    ops._VAE_ATTN_WS.clear()
+    assert rel_l2(again, ref) < 2e-3
 
 
 def test_gemm_f16_bias_and_residual():

@@ -74,11 +74,16 @@ def groupnorm(x, gamma, beta, groups, eps=1e-6, silu=True, out=None):
     return groupnorm_apply(x, groupnorm_stats(x, groups, eps), gamma, beta, groups, silu, out)
 
 
-def softmax_framecausal_(scores, tokens_per_frame, scale):
-    rows, cols = scores.shape
-    r = torch.arange(rows)
-    valid = torch.minimum((r // tokens_per_frame + 1) * tokens_per_frame, torch.tensor(cols))
-    mask = torch.arange(cols)[None, :] < valid[:, None]
-    s = (scores.float() * scale).masked_fill(~mask, float("-inf"))
-    scores.copy_(torch.softmax(s, dim=-1).masked_fill(~mask, 0.0).to(scores.dtype))
-    return scores
+def attention_framecausal(q, k, vt, q_per_frame, k_per_frame, out=None, scale=1.0):
+    Sq, C = q.shape
+    T = Sq // q_per_frame
+    Sk = T * k_per_frame
+    s = q.float() @ k[:Sk].float().t() * scale
+    valid = (torch.arange(Sq) // q_per_frame + 1) * k_per_frame
+    mask = torch.arange(Sk)[None, :] < valid[:, None]
+    p = torch.softmax(s.masked_fill(~mask, float("-inf")), dim=-1).to(F16)
+    y = (p.float() @ vt[:, :Sk].float().t()).to(F16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
