@@ -50,6 +50,7 @@ constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
 // with gm = 2, and the K = 3072 ones of middling width (qkv, ff1) lose 2-3 % with anything but 8.
 struct ConvGeom {
     int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw, dt, dh, dw, hmax, wmax, gm;
+    int lcin;      // log2(Cin) (gemm_w4.h's gather: Cin is a power of two there)
 };
 
 // OCP e4m3 storage type of the fp8 path (K6): one byte per element, so a 128-B LDS row holds 128 K values.

@@ -91,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr bool SCALED = sizeof(T) == 1;
     constexpr int BKE = 128 / (int)sizeof(T);
     constexpr int CE = 16 / (int)sizeof(T);
+    constexpr int LOG2_CE = CE == 16 ? 4 : 3;       // elements per 16-byte chunk
     constexpr int KS = mfma_op<T>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A[2] 32 KiB each | W[2] | stage 32 KiB
     constexpr unsigned W_BASE = 2 * OP_BYTES;
@@ -107,7 +108,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     unsigned pa[2][4], pw[8];
     const char *abase = nullptr, *wbase = nullptr;
     int arow0[2][4], wrow0[8];
-    unsigned cpos[2][4];        // AMODE 1: centre tap of each DMA row in tap coordinates, packed t << 22 | h << 11 | w
+    // AMODE 1 (convolution gather), per DMA row of the tile: coff = source of the CENTRE tap in 16-byte units from the
+    // volume's start (the lane's swizzled chunk included); ccode = nine 2-bit signed voxel steps, [2 i] for the time
+    // taps dt = i - 2, [6 + 2 i] for dh = i - 1, [12 + 2 i] for dw = i - 1: how far the clamped (replicate padding,
+    // causal in time), stride-folded source coordinate of that tap lies from the centre's, each in {-2 .. 1}.
+    // A K tile's source is then three field extracts and two multiply-adds away (uniform tap), instead of the
+    // clamps, shifts and 64-bit multiplies per piece and K tile that made the gather the longest stream of the loop.
+    unsigned coff[2][4], ccode[2][4];
     int m0 = 0, n0 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -150,8 +157,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     pa[h][j] = (unsigned)(min(m0 + ar, M - 1) - m0) * (unsigned)(lda * sizeof(T)) + (pch ^ ((ar >> 1) & 7)) * 16;
                 } else {
                     const int m = min(m0 + ar, M - 1);
-                    cpos[h][j] = (unsigned)((m % cg.Wo) << cg.dw) | ((unsigned)(((m / cg.Wo) % cg.Ho) << cg.dh) << 11) |
-                                 ((unsigned)((m / (cg.Wo * cg.Ho)) << cg.dt) << 22);
+                    const int wc = (m % cg.Wo) << cg.dw, hc = ((m / cg.Wo) % cg.Ho) << cg.dh,
+                              tc = (m / (cg.Wo * cg.Ho)) << cg.dt;
+                    auto src_t = [&](int x) { x = max(x, 0); return cg.st ? ((x + 1) >> 1) : x; };
+                    auto src_h = [&](int y) { return min(max(y, 0), cg.hmax) >> cg.sh; };
+                    auto src_w = [&](int x) { return min(max(x, 0), cg.wmax) >> cg.sw; };
+                    const int t0 = src_t(tc), h0 = src_h(hc), w0 = src_w(wc);
+                    unsigned code = 0;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        code |= (unsigned)((src_t(tc + i - 2) - t0) & 3) << (2 * i);
+                        code |= (unsigned)((src_h(hc + i - 1) - h0) & 3) << (6 + 2 * i);
+                        code |= (unsigned)((src_w(wc + i - 1) - w0) & 3) << (12 + 2 * i);
+                    }
+                    ccode[h][j] = code;
+                    // the row's swizzle term is (prow >> 1) | 4 (j & 1)  (rows come 8 per instruction)
+                    const unsigned chunk = (unsigned)(pch ^ (prow >> 1) ^ ((j & 1) << 2));
+                    coff[h][j] = ((unsigned)((t0 * cg.Hi + h0) * cg.Wi + w0) << (cg.lcin - LOG2_CE)) + chunk;
                 }
             }
 #pragma unroll
@@ -171,17 +193,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             return reinterpret_cast<const T*>(abase + koff * (int64_t)sizeof(T) + pa[h][j]);
         } else {
             const int k0 = t * BKE;
-            const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
-            const int dt = tap / 9 - 2, dh = (tap / 3) % 3 - 1, dw = tap % 3 - 1;
-            const int tu = max((int)(cpos[h][j] >> 22) + dt, 0);
-            const int hu = min(max((int)((cpos[h][j] >> 11) & 2047) + dh, 0), cg.hmax);
-            const int wu = min(max((int)(cpos[h][j] & 2047) + dw, 0), cg.wmax);
-            // source chunk of this lane: the row's swizzle term is (prow >> 1) | 4 (j & 1)  (rows come 8 per instruction)
-            const int cch = (pch ^ (prow >> 1) ^ ((j & 1) << 2)) * CE;
-            const int ts = cg.st ? ((tu + 1) >> 1) : tu;
-            const int hs = hu >> cg.sh, ws = wu >> cg.sw;
-            const int64_t off = ((int64_t)(ts * cg.Hi + hs) * cg.Wi + ws) * cg.Cin + c0 + cch;
-            return A + off;
+            const int tap = k0 >> cg.lcin, c0 = k0 & (cg.Cin - 1);                   // (uniform)
+            const int it = tap / 9, ih = (tap / 3) % 3, iw = tap % 3;
+            const int code = (int)ccode[h][j];
+            const int dT = __builtin_amdgcn_sbfe(code, 2 * it, 2), dH = __builtin_amdgcn_sbfe(code, 6 + 2 * ih, 2),
+                      dW = __builtin_amdgcn_sbfe(code, 12 + 2 * iw, 2);
+            const int dvox = __mul24(dT, cg.Hi * cg.Wi) + __mul24(dH, cg.Wi) + dW;
+            const unsigned off16 = coff[h][j] + ((unsigned)dvox << (cg.lcin - LOG2_CE));
+            return reinterpret_cast<const T*>(reinterpret_cast<const char*>(A + c0) + ((uint64_t)off16 << 4));
         }
     };
     auto src_w = [&](int j, int t) __attribute__((always_inline)) -> const T* {

@@ -64,6 +64,11 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
     // centre taps are packed t << 22 | h << 11 | w in gemm_w4.h, in tap coordinates (strided: twice the output's)
     FP_REQUIRE((cg.To << cg.dt) < 1024 && (cg.Ho << cg.dh) < 2048 && (cg.Wo << cg.dw) < 2048);
     const int M = (int)M64, N = Cout, K = 27 * cg.Cin;
+    // the 4-wave kernel's gather: Cin a power of two (voxel steps become shifts), 24-bit multiplies of the plane and
+    // row pitch in voxels, sources addressed in 16-byte units from the volume's start
+    FP_REQUIRE((cg.Cin & (cg.Cin - 1)) == 0 && (int64_t)cg.Hi * cg.Wi < (1 << 23) &&
+               (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin * 2 / 16 < (1ll << 32));
+    FP_REQUIRE(cg.lcin == __builtin_ctz((unsigned)cg.Cin));
     FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + 31) / 32) < (1ll << 31));
     const bool wide = ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
     // Cout <= 128 / <= 32 (the last up block and conv_out): the narrow tiles of gemm_w4.h
@@ -95,6 +100,7 @@ extern "C" int fp_conv3d_causal_f16(const void* x, const void* w, const void* bi
     cg.To = up_t == 2 ? 2 * Ti - 1 : Ti; cg.Ho = Hi * up_h; cg.Wo = Wi * up_w;
     cg.Cin = Cin; cg.st = up_t - 1; cg.sh = up_h - 1; cg.sw = up_w - 1;
     cg.hmax = cg.Ho - 1; cg.wmax = cg.Wo - 1;
+    cg.lcin = __builtin_ctz((unsigned)Cin);
     return conv_launch(x, w, bias, y, cg, Cout, resid, (hipStream_t)stream);
 }
 
@@ -113,6 +119,7 @@ extern "C" int fp_conv3d_causal_strided_f16(const void* x, const void* w, const 
     cg.To = (Ti - 1) / dn_t + 1; cg.Ho = (Hi - 1) / dn_h + 1; cg.Wo = (Wi - 1) / dn_w + 1;
     cg.Cin = Cin; cg.dt = dn_t - 1; cg.dh = dn_h - 1; cg.dw = dn_w - 1;
     cg.hmax = Hi - 1; cg.wmax = Wi - 1;
+    cg.lcin = __builtin_ctz((unsigned)Cin);
     return conv_launch(x, w, bias, y, cg, Cout, nullptr, (hipStream_t)stream);
 }
 

@@ -1,5 +1,7 @@
 """Per-rank compute of one DiT step under Ulysses sequence parallelism, emulated on ONE GPU: the GEMMs at the rank's
-row count and the attention at the rank's head count (the exchange itself is not in here).
+row count, the attention at the rank's head count, and the two copy passes the exchange still needs (packing q|k|v
+into the per-peer send layout, unpacking the returned heads into the projection's input; the attention output itself
+is written straight into the inverse exchange's send buffer).  The all-to-all itself cannot be measured on one GPU.
 usage: sp_shape_probe.py [P ...]"""
 import math
 import os
@@ -53,6 +55,16 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     h = 24 // P
     q, k, v = rnd(S, h * 128), rnd(S, h * 128), rnd(S, h * 128)
     t["attention x60"] = 60 * timed(lambda: ops.attention(q, k, v, h), n=4)
+    if P > 1:
+        from framepack_amd.ulysses import pick_chunks
+        ch = pick_chunks(S, h)
+        hwc = h // ch * 128
+        ql, kl, vl = o9[:, :3072], o9[:, 3072:6144], o9[:, 6144:]            # the q|k|v GEMM's output, row stride 9216
+        t[f"pack x60 ({ch} chunks)"] = 60 * timed(lambda: torch.stack(
+            [x.reshape(n, P, ch, hwc) for x in (ql, kl, vl)], dim=3).permute(2, 1, 0, 3, 4).contiguous())
+        recv = rnd(P, n, hwc)
+        t["unpack x60"] = 60 * timed(lambda: [o3.unflatten(1, (P, ch, hwc))[:, :, c].copy_(recv.permute(1, 0, 2))
+                                              for c in range(ch)])
     tot = sum(t.values())
     base = base or tot * P
     print(f"P={P} rows/rank {n} heads/rank {h}: " + " | ".join(f"{k} {v:.1f}" for k, v in t.items()) +
