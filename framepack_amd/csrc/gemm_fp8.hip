@@ -65,7 +65,101 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const bf16* __restri
         *reinterpret_cast<u32x2*>(qr + K1 + k) = quant8(*reinterpret_cast<const bf16x8*>(r2 + k), inv);
 }
 
+// K3 + K6a in one pass (the A operand of the q|k|v, ff1 and single-block in-projection GEMMs in fp8 compute mode):
+// y = LN(x) * (1 + scale) + shift rounded to bf16 as fp_layernorm_modulate_bf16 writes it, then quantised per row as
+// fp_quantize_rows_fp8 does - bit-identical to the two calls, without the bf16 row ever reaching memory.
+// One wave per token row, the row in registers (NCH chunks of 512 elements).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_modulate_fp8_kernel(const bf16* __restrict__ x, int64_t x_rs,
+                                                              const bf16* __restrict__ scale,
+                                                              const bf16* __restrict__ shift,
+                                                              unsigned char* __restrict__ q, int64_t ldq,
+                                                              float* __restrict__ q_scale, int rows, int cols,
+                                                              float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16* xr = x + (int64_t)row * x_rs;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < cols) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(xr + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[c][j] = (float)t[j];
+                s += v[c][j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)cols;
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < cols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[c][j] - mean;
+                ss += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)cols + eps);
+    bf16x8 o[NCH];
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < cols) {
+            const bf16x8 sc = *reinterpret_cast<const bf16x8*>(scale + col);
+            const bf16x8 sh = *reinterpret_cast<const bf16x8*>(shift + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                o[c][j] = (bf16)((v[c][j] - mean) * rstd * (1.f + (float)sc[j]) + (float)sh[j]);
+            m = amax8(o[c], m);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    const float qs = m > 0.f ? m * (1.f / FP8_MAX) : 1.f;
+    const float inv = 1.f / qs;
+    if (lane == 0) q_scale[row] = qs;
+    unsigned char* qr = q + (int64_t)row * ldq;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int col = c * 512 + lane * 8;
+        if (col < cols) *reinterpret_cast<u32x2*>(qr + col) = quant8(o[c], inv);
+    }
+}
+
 }  // namespace
+
+extern "C" int fp_layernorm_modulate_fp8(const void* x, int64_t x_row_stride, const void* scale, const void* shift,
+                                         void* q, int64_t ldq, void* q_scale, int rows, int cols, float eps,
+                                         void* stream) {
+    FP_REQUIRE(x && scale && shift && q && q_scale && rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096);
+    FP_REQUIRE(x_row_stride % 8 == 0 && x_row_stride >= cols && ldq % 8 == 0 && ldq >= cols);
+    FP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0 &&
+               ((uintptr_t)q & 7) == 0 && ((uintptr_t)q_scale & 3) == 0);
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((rows + 3) / 4), block(256);
+    const bf16 *xp = (const bf16*)x, *sc = (const bf16*)scale, *sh = (const bf16*)shift;
+    if (cols <= 512)
+        ln_modulate_fp8_kernel<1><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, (unsigned char*)q, ldq, (float*)q_scale, rows, cols, eps);
+    else if (cols <= 3072)
+        ln_modulate_fp8_kernel<6><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, (unsigned char*)q, ldq, (float*)q_scale, rows, cols, eps);
+    else
+        ln_modulate_fp8_kernel<8><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, (unsigned char*)q, ldq, (float*)q_scale, rows, cols, eps);
+    FP_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int fp_quantize_rows_fp8(const void* x1, int64_t ld1, int K1, const void* x2, int64_t ld2, int K2,
                                     void* q, int64_t ldq, void* scale, int M, void* stream) {

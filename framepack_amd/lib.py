@@ -37,6 +37,7 @@ SIGNATURES = {
     "fp_debug_gemm_variant": [I],
     "fp_debug_attn_variant": [I],
     "fp_quantize_rows_fp8": [P, L, I, P, L, I, P, L, P, I, P],
+    "fp_layernorm_modulate_fp8": [P, L, P, P, P, L, P, I, I, F, P],
     "fp_gemm_fp8_bf16": [P, L, P, P, L, P, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_conv3d_causal_f16": [P, P, P, P, I, I, I, I, I, I, I, I, P, P],
     "fp_conv3d_causal_strided_f16": [P, P, P, P, I, I, I, I, I, I, I, I, P],

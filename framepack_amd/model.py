@@ -651,26 +651,33 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         aq, asc = ops.quantize_rows_fp8(a, out=ws.Q[:M * K].view(M, K), scale=ws.QS[:M])
         return ops.gemm_fp8(aq, asc, w[0], w[1], b, **kw)
 
+    @staticmethod
+    def _ln_lin(ws, x, sc, sh, n, w, b, **kw):
+        """LayerNorm+modulate of the rows x followed by one block linear.  bf16: K3 into n, then the GEMM.  fp8 compute:
+        the fused K3 + row quantiser writes the GEMM's e4m3 operand directly (n is not touched)."""
+        if not isinstance(w, tuple):
+            ops.layernorm_modulate(x, sc, sh, out=n)
+            return ops.gemm(n, w, b, **kw)
+        M, K = x.shape
+        aq, asc = ops.layernorm_modulate_fp8(x, sc, sh, out=ws.Q[:M * K].view(M, K), out_scale=ws.QS[:M])
+        return ops.gemm_fp8(aq, asc, w[0], w[1], b, **kw)
+
     def _double_block(self, e, mod_i, mod_c, ws, Si, S, rope):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod_i.chunk(6)
         csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = mod_c.chunk(6)
-        ops.layernorm_modulate(X[:Si], sc_a, sh_a, out=N[:Si])
-        ops.layernorm_modulate(X[Si:], csc_a, csh_a, out=N[Si:])
         qkv = Y[:, :3 * d]
-        self._lin(ws, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
-        self._lin(ws, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
+        self._ln_lin(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
+        self._ln_lin(ws, X[Si:], csc_a, csh_a, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
         q, k, v = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
         ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H, wq_txt=e.nq_c, wk_txt=e.nk_c)
         self._attend(q, k, v, Si)
         self._lin(ws, q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
         self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
-        ops.layernorm_modulate(X[:Si], sc_m, sh_m, out=N[:Si])
-        ops.layernorm_modulate(X[Si:], csc_m, csh_m, out=N[Si:])
         Fh = Y[:, 3 * d:]
-        self._lin(ws, N[:Si], e.w_ff1, e.b_ff1, out=Fh[:Si], epilogue=ops.EPI_GELU)
-        self._lin(ws, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
+        self._ln_lin(ws, X[:Si], sc_m, sh_m, N[:Si], e.w_ff1, e.b_ff1, out=Fh[:Si], epilogue=ops.EPI_GELU)
+        self._ln_lin(ws, X[Si:], csc_m, csh_m, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
         self._lin(ws, Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_m)
         self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_m)
 
@@ -678,8 +685,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         shift, scale, gate = mod.chunk(3)
-        ops.layernorm_modulate(X, scale, shift, out=N)
-        self._lin(ws, N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)   # [k | v | q | gelu(mlp)]
+        self._ln_lin(ws, X, scale, shift, N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM,
+                     gelu_from=3 * d)                                                       # [k | v | q | gelu(mlp)]
         k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
         ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H)
         self._attend(q, k, v, Si)

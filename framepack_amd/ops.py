@@ -328,6 +328,30 @@ def quantize_rows_fp8(x: torch.Tensor, x2: Optional[torch.Tensor] = None, out: O
     return out, scale
 
 
+def layernorm_modulate_fp8(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, eps: float = 1e-6,
+                           out: Optional[torch.Tensor] = None, out_scale: Optional[torch.Tensor] = None):
+    """K3 + K6a in one pass: (e4m3 [rows, cols], fp32 scale [rows]) of LN(x) * (1 + scale) + shift - what
+    `quantize_rows_fp8(layernorm_modulate(x, scale, shift))` returns, bit for bit."""
+    _dev(x, scale, shift, out, out_scale)
+    x2, rows, cols, xs = _rows2d(x)
+    assert x.dtype == BF16
+    if out is None:
+        out = torch.empty((rows, cols), dtype=FP8, device=x.device)
+    if out_scale is None:
+        out_scale = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    assert out.dtype == FP8 and tuple(out.shape) == (rows, cols) and (rows == 0 or out.stride(1) == 1)
+    assert out_scale.dtype == torch.float32 and out_scale.numel() == rows and out_scale.is_contiguous()
+    scale = scale.reshape(-1).contiguous()
+    shift = shift.reshape(-1).contiguous()
+    assert scale.numel() == cols and shift.numel() == cols and scale.dtype == BF16 and shift.dtype == BF16
+    if rows == 0:
+        return out, out_scale
+    _lib.check(_lib.load().fp_layernorm_modulate_fp8(x2.data_ptr(), xs, scale.data_ptr(), shift.data_ptr(),
+                                                     out.data_ptr(), out.stride(0), out_scale.data_ptr(), rows, cols,
+                                                     eps, _stream(x)), "fp_layernorm_modulate_fp8")
+    return out, out_scale
+
+
 def gemm_fp8(a_q: torch.Tensor, a_scale: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor,
              bias: Optional[torch.Tensor], out: Optional[torch.Tensor] = None, epilogue: int = EPI_BIAS,
              gelu_from: int = 0, resid: Optional[torch.Tensor] = None,

@@ -128,6 +128,13 @@ int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void*
  * weight * scale_weight, then F.linear) with a GEMM that multiplies in e4m3.  Opt-in: quantised activations move
  * a block's output by 2-4 % relative L2, outside the 1e-2 bar of the bf16 path. */
 
+/* K3 + K6a fused (fp8 compute mode; no reference counterpart beyond the two it fuses): the e4m3 row and its scale
+ * that fp_quantize_rows_fp8 would produce from the output of fp_layernorm_modulate_bf16 (ref :453, :476, :642-643),
+ * bit-identical to the two calls, in one pass over x.  q: e4m3 [rows, cols] with row stride ldq bytes; q_scale: fp32
+ * [rows]; cols % 8 == 0, cols <= 4096. */
+int fp_layernorm_modulate_fp8(const void* x, int64_t x_row_stride, const void* scale, const void* shift, void* q,
+                              int64_t ldq, void* q_scale, int rows, int cols, float eps, void* stream);
+
 /* x1 [M, K1] (and optionally x2 [M, K2], laid after it in K) bf16 -> q [M, K1+K2] e4m3 (OCP, max 448) and
  * scale [M] fp32 with x ~= scale[m] * q.  K1, K2 % 8 == 0; ldq (bytes = elements) % 8 == 0 (% 16 to feed fp_gemm_fp8_bf16). */
 int fp_quantize_rows_fp8(const void* x1, int64_t ld1, int K1, const void* x2, int64_t ld2, int K2, void* q,

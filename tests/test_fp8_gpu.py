@@ -53,6 +53,29 @@ def test_quantize_rows_zero_row_and_strided():
     assert sc[2].item() == 1.0 and q[2].float().abs().sum().item() == 0.0
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 8), (5, 256), (301, 3072), (19, 4096), (6, 520)])
+def test_fused_layernorm_modulate_quantiser_equals_the_two_passes(rows, cols):
+    x = randn(rows, cols, seed=11, scale=2.0).bfloat16()
+    x[0, 0] = 60.0
+    if rows > 2:
+        x[2] = 1.5                                          # a constant row: LN gives 0, the row is its shift
+    sc, sh = randn(cols, seed=12, scale=0.3).bfloat16(), randn(cols, seed=13, scale=0.3).bfloat16()
+    want_q, want_s = ops.quantize_rows_fp8(ops.layernorm_modulate(x, sc, sh))
+    q, s_ = ops.layernorm_modulate_fp8(x, sc, sh)
+    assert torch.equal(s_, want_s) and torch.equal(q.view(torch.uint8), want_q.view(torch.uint8))
+    # row-strided input and output (the model's views), zero shift and scale on an all-equal row -> scale 1, zeros
+    big = torch.zeros(rows, cols + 64, dtype=torch.bfloat16, device=DEV)
+    big[:, 32:32 + cols] = x
+    qbuf = torch.full((rows, cols + 16), 9, dtype=torch.uint8, device=DEV).view(ops.FP8)
+    q2, s2 = ops.layernorm_modulate_fp8(big[:, 32:32 + cols], sc, sh, out=qbuf[:, :cols])
+    assert torch.equal(s2, want_s) and torch.equal(q2.view(torch.uint8), want_q.view(torch.uint8))
+    assert (qbuf.view(torch.uint8)[:, cols:] == 9).all()
+    if rows > 2:
+        z = torch.zeros(cols, dtype=torch.bfloat16, device=DEV)
+        q3, s3 = ops.layernorm_modulate_fp8(x, z, z)
+        assert s3[2].item() == 1.0 and q3[2].float().abs().sum().item() == 0.0
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (1, 8, 128), (300, 768, 256), (1408, 1792, 384), (777, 3072, 3072),
                                    (19385, 3072, 1024)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
