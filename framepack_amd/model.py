@@ -413,7 +413,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
     def invalidate_step_invariants(self):
         """Drop the cross-step caches (clean-latent embeddings, image projection, mask facts).  They are keyed by
         tensor identity and version counter; GPU tensors made under torch.inference_mode carry no version counter, so
-        after writing INTO such a tensor between steps call this (the section driver calls it per section)."""
+        after writing INTO such a tensor between steps call this (`sampler.sample_hunyuan` calls it at the start of every
+        section)."""
         self._invariant = {}
 
     def enable_fp8_compute(self, enable: bool = True):

@@ -198,6 +198,10 @@ def sample_hunyuan(transformer, sampler="unipc", initial_latent=None, concat_lat
     seq_length = T * H * W // 4
     mu = calculate_flux_mu(seq_length, exp_max=7.0) if shift is None else math.log(shift)
     sigmas = get_flux_sigmas_from_mu(num_inference_steps, mu).to(device)
+    # a new section: new clean latents and embeddings.  The model keys its cross-step caches by tensor identity and
+    # version; dropping them here also covers GPU tensors edited in place under inference_mode (no version counter)
+    if hasattr(transformer, "invalidate_step_invariants"):
+        transformer.invalidate_step_invariants()
     k_model = fm_wrapper(transformer)
     if initial_latent is not None:
         sigmas = sigmas * strength
