@@ -96,7 +96,11 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(bf16* __restrict__ x
 //     reference: bf16 after the normalisation, bf16 after the weight, bf16 after the rotation.
 //     Rows >= rope_rows (the text tokens) use the second weight pair when one is given
 //     (norm_added_q / norm_added_k of the double-stream blocks).
+//     PACK (Ulysses sequence parallelism): q, k and v are read-only and the results - v copied as it is - go to
+//     `pack`, the send buffer of the head exchange, laid out [chunk][peer][row][q|k|v][heads per chunk x 128]: head h
+//     belongs to peer h / hl, chunk (h % hl) / hc.  The exchange then needs no packing pass of its own.
 // ---------------------------------------------------------------------------------------------
+template <bool PACK>
 __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(bf16* __restrict__ q, bf16* __restrict__ k,
                                                               int64_t row_stride, int rows, int heads,
                                                               const bf16* __restrict__ wq,
@@ -104,16 +108,27 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(bf16* __restrict__
                                                               const bf16* __restrict__ wq_txt,
                                                               const bf16* __restrict__ wk_txt,
                                                               const float* __restrict__ rope, int rope_rows,
-                                                              float eps) {
+                                                              float eps, const bf16* __restrict__ v,
+                                                              bf16* __restrict__ pack, int hl, int hc) {
     const int sub = threadIdx.x & 15;                        // 16-B chunk of the 128-wide head row
     const int64_t item = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // (row, which, head)
-    const int per_row = 2 * heads;
+    const int per_row = (PACK ? 3 : 2) * heads;
     const int64_t nitems = (int64_t)rows * per_row;
     if (item >= nitems) return;                              // whole 16-lane groups leave together
     const int row = (int)(item / per_row);
     const int rem = (int)(item % per_row);
     const int which = rem / heads, head = rem % heads;
-    bf16* base = (which ? k : q) + (int64_t)row * row_stride + head * 128 + sub * 8;
+    bf16* base = (which == 0 ? q : (which == 1 ? k : const_cast<bf16*>(v))) + (int64_t)row * row_stride + head * 128 + sub * 8;
+    bf16* dst = base;
+    if (PACK) {
+        const int peer = head / hl, chunk = (head % hl) / hc, hi = head % hc;
+        const int world = heads / hl;
+        dst = pack + ((((int64_t)chunk * world + peer) * rows + row) * 3 + which) * (hc * 128) + hi * 128 + sub * 8;
+        if (which == 2) {
+            *reinterpret_cast<bf16x8*>(dst) = *reinterpret_cast<const bf16x8*>(base);
+            return;
+        }
+    }
     const bool is_txt = row >= rope_rows;
     const bf16* w = which ? ((is_txt && wk_txt) ? wk_txt : wk) : ((is_txt && wq_txt) ? wq_txt : wq);
 
@@ -149,7 +164,7 @@ __global__ __launch_bounds__(256) void qk_rmsnorm_rope_kernel(bf16* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (bf16)n[j];
     }
-    *reinterpret_cast<bf16x8*>(base) = o;
+    *reinterpret_cast<bf16x8*>(dst) = o;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -301,9 +316,31 @@ extern "C" int fp_qk_rmsnorm_rope_bf16(void* q, void* k, int64_t row_stride, int
     FP_REQUIRE((!wq_txt || aligned16(wq_txt)) && (!wk_txt || aligned16(wk_txt)));
     if (rows == 0) return 0;
     const int64_t items = (int64_t)rows * 2 * heads;
-    qk_rmsnorm_rope_kernel<<<(unsigned)((items + 15) / 16), 256, 0, (hipStream_t)stream>>>(
+    qk_rmsnorm_rope_kernel<false><<<(unsigned)((items + 15) / 16), 256, 0, (hipStream_t)stream>>>(
         (bf16*)q, (bf16*)k, row_stride, rows, heads, (const bf16*)wq, (const bf16*)wk, (const bf16*)wq_txt,
-        (const bf16*)wk_txt, rope, rope_rows, eps);
+        (const bf16*)wk_txt, rope, rope_rows, eps, nullptr, nullptr, heads, heads);
+    FP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int fp_qk_rmsnorm_rope_pack_bf16(const void* q, const void* k, const void* v, int64_t row_stride, int rows,
+                                            int heads, int head_dim, const void* wq, const void* wk,
+                                            const void* wq_txt, const void* wk_txt, const float* rope, int rope_rows,
+                                            float eps, void* pack, int world, int chunks, void* stream) {
+    FP_REQUIRE(q && k && v && pack && wq && wk && rows >= 0 && heads > 0 && head_dim == 128);
+    FP_REQUIRE(world >= 1 && chunks >= 1 && heads % (world * chunks) == 0);
+    FP_REQUIRE(row_stride % 8 == 0 && row_stride >= (int64_t)heads * 128);
+    FP_REQUIRE(rope_rows >= 0 && rope_rows <= rows && (rope_rows == 0 || rope));
+    FP_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(pack) && aligned16(wq) && aligned16(wk) &&
+               aligned16(rope));
+    FP_REQUIRE((!wq_txt || aligned16(wq_txt)) && (!wk_txt || aligned16(wk_txt)));
+    if (rows == 0) return 0;
+    const int64_t items = (int64_t)rows * 3 * heads;
+    const int hl = heads / world, hc = hl / chunks;
+    qk_rmsnorm_rope_kernel<true><<<(unsigned)((items + 15) / 16), 256, 0, (hipStream_t)stream>>>(
+        const_cast<bf16*>((const bf16*)q), const_cast<bf16*>((const bf16*)k), row_stride, rows, heads, (const bf16*)wq,
+        (const bf16*)wk, (const bf16*)wq_txt, (const bf16*)wk_txt, rope, rope_rows, eps, (const bf16*)v, (bf16*)pack,
+        hl, hc);
     FP_CHECK_LAUNCH();
     return 0;
 }

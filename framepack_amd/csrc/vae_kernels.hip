@@ -184,23 +184,33 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
 }
 
-// y = f((x - mean_g) * rstd_g * gamma_c + beta_c),  f = SiLU or identity
+// y = f((x - mean_g) * rstd_g * gamma_c + beta_c),  f = SiLU or identity.
+// The grid's stride (gridDim.x * 256 chunks) is a multiple of the chunks per row (C / 8, a power of two <= 256), so a
+// thread keeps its 8 channels for all its rows: their scale a = rstd * gamma and offset b = beta - mean * a are
+// computed once, and a row costs one 16-byte load, 8 fma (+ SiLU: exp2, add, rcp, mul) and one 16-byte store.
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t n8,
                                                        int C, int groups, const float* __restrict__ stats,
                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta) {
     const int chunks = C >> 3, gs = C / groups;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % chunks) * 8;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c0 = (int)(i0 % chunks) * 8;
+    const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c0);
+    const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c0);
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int g = (c0 + j) / gs;
+        a[j] = stats[2 * g + 1] * (float)gm[j];
+        b[j] = (float)bt[j] - stats[2 * g] * a[j];
+    }
+    for (int64_t i = i0; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
         const f16x8 v = *reinterpret_cast<const f16x8*>(x + i * 8);
-        const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c0);
-        const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c0);
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int g = (c0 + j) / gs;
-            float t = ((float)v[j] - stats[2 * g]) * stats[2 * g + 1] * (float)gm[j] + (float)bt[j];
-            if (SILU) t = t / (1.f + __expf(-t));
+            float t = __builtin_fmaf((float)v[j], a[j], b[j]);
+            if (SILU) t = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
             o[j] = (f16)t;
         }
         *reinterpret_cast<f16x8*>(y + i * 8) = o;
@@ -293,6 +303,7 @@ extern "C" int fp_groupnorm_stats_f16(const void* x, int64_t rows, int C, int gr
 extern "C" int fp_groupnorm_apply_f16(const void* x, void* y, int64_t rows, int C, int groups, const float* stats,
                                       const void* gamma, const void* beta, int silu, void* stream) {
     FP_REQUIRE(x && y && stats && gamma && beta && rows > 0 && C % 8 == 0 && groups > 0 && C % groups == 0);
+    FP_REQUIRE((C / 8) <= 256 && ((C / 8) & (C / 8 - 1)) == 0);        // a thread keeps its channels (kernel comment)
     FP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 &&
                ((uintptr_t)beta & 15) == 0);
     const int64_t n8 = rows * (C / 8);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "fp_attn_fp8_varlen_workspace_bytes": [I, I, I, I],
     "fp_attn_fwd_fp8_varlen": [P, P, P, P, L, L, L, L, P, I, I, I, I, I, F, P, L, P],
     "fp_qk_rmsnorm_rope_bf16": [P, P, L, I, I, I, P, P, P, P, P, I, F, P],
+    "fp_qk_rmsnorm_rope_pack_bf16": [P, P, P, L, I, I, I, P, P, P, P, P, I, F, P, I, I, P],
     "fp_layernorm_modulate_bf16": [P, L, P, P, P, L, I, I, F, P],
     "fp_gate_residual_bf16": [P, L, P, L, P, I, I, P],
     "fp_silu_gemv_bf16": [P, P, P, P, I, I, I, P],

@@ -437,16 +437,23 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.fp8_attention = bool(enable)
         return self
 
-    def _attend(self, q, k, v, n_img):
-        """Joint attention over [image rows | text rows]; output written over q."""
+    def _qk_attend(self, q, k, v, wq, wk, rope, n_img, wq_txt=None, wk_txt=None):
+        """K2 (RMSNorm of q and k per head, RoPE on the image rows) and the joint attention over [image rows | text
+        rows]; output written over q.  Under sequence parallelism K2 writes its results and v straight into the send
+        buffer of the head exchange (q, k, v themselves stay raw: only the attention output lands in q)."""
         attn = ops.attention_fp8 if self.fp8_attention else ops.attention
         if self.sp_world == 1:
+            ops.qk_rmsnorm_rope_(q, k, wq, wk, rope, n_img, self.heads, wq_txt=wq_txt, wk_txt=wk_txt)
             attn(q, k, v, self.heads, out=q)
         else:
-            from .ulysses import ulysses_attention
+            from .ulysses import pick_chunks, ulysses_attention
+            hl = self.heads // self.sp_world
+            chunks = self.sp_chunks if self.sp_chunks is not None else pick_chunks(self._sp_total, hl)
+            packed = ops.qk_rmsnorm_rope_pack(q, k, v, wq, wk, rope, n_img, self.heads, self.sp_world, chunks,
+                                              wq_txt=wq_txt, wk_txt=wk_txt)
             ulysses_attention(q, k, v, self._sp_total, self.heads, self.head_dim,
                               lambda jq, jk, jv, h, o: attn(jq, jk, jv, h, out=o), self.sp_group, out=q,
-                              chunks=self.sp_chunks)
+                              chunks=chunks, packed=packed)
 
     @property
     def device(self):
@@ -672,8 +679,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ln_lin(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
         self._ln_lin(ws, X[Si:], csc_a, csh_a, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
         q, k, v = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
-        ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H, wq_txt=e.nq_c, wk_txt=e.nk_c)
-        self._attend(q, k, v, Si)
+        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, wq_txt=e.nq_c, wk_txt=e.nk_c)
         self._lin(ws, q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
         self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
         Fh = Y[:, 3 * d:]
@@ -689,8 +695,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ln_lin(ws, X, scale, shift, N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM,
                      gelu_from=3 * d)                                                       # [k | v | q | gelu(mlp)]
         k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
-        ops.qk_rmsnorm_rope_(q, k, e.nq, e.nk, rope, Si, H)
-        self._attend(q, k, v, Si)
+        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si)
         self._lin(ws, Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
 
     def _run_blocks(self, P, mods, ws, Si, S, rope):

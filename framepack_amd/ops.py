@@ -109,6 +109,35 @@ def qk_rmsnorm_rope_(q: torch.Tensor, k: torch.Tensor, wq: torch.Tensor, wk: tor
                "fp_qk_rmsnorm_rope_bf16")
 
 
+def qk_rmsnorm_rope_pack(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor,
+                         rope: Optional[torch.Tensor], rope_rows: int, heads: int, world: int, chunks: int,
+                         eps: float = 1e-6, wq_txt: Optional[torch.Tensor] = None,
+                         wk_txt: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K2 for sequence parallelism: q, k, v [rows, heads*128] (one row stride) are left as they are; returns the send
+    buffer of the head exchange [chunks, world, rows, 3 * hc * 128] holding RMSNorm/RoPE(q), RMSNorm/RoPE(k) and v of
+    the heads each peer owns (hc = heads / world / chunks heads per chunk)."""
+    _dev(q, k, v, wq, wk, rope, wq_txt, wk_txt, out)
+    q2, rows, cols, qs = _rows2d(q)
+    k2, kr, kc, ks = _rows2d(k)
+    v2, vr, vc, vs = _rows2d(v)
+    assert (kr, kc) == (rows, cols) and (vr, vc) == (rows, cols) and qs == ks == vs and cols == heads * 128
+    assert q.dtype == BF16 and k.dtype == BF16 and v.dtype == BF16 and heads % (world * chunks) == 0
+    for w in (wq, wk, wq_txt, wk_txt):
+        assert w is None or (w.dtype == BF16 and w.numel() == 128 and w.is_contiguous())
+    if rope_rows > 0:
+        assert rope is not None and rope.dtype == torch.float32 and rope.is_contiguous()
+        assert rope.shape[-1] == 256 and rope.numel() >= rope_rows * 256
+    hwc = heads // world // chunks * 128
+    if out is None:
+        out = torch.empty((chunks, world, rows, 3 * hwc), dtype=BF16, device=q.device)
+    assert tuple(out.shape) == (chunks, world, rows, 3 * hwc) and out.is_contiguous() and out.dtype == BF16
+    _lib.check(_lib.load().fp_qk_rmsnorm_rope_pack_bf16(q2.data_ptr(), k2.data_ptr(), v2.data_ptr(), qs, rows, heads, 128,
+                                                        wq.data_ptr(), wk.data_ptr(), _ptr(wq_txt), _ptr(wk_txt),
+                                                        _ptr(rope), rope_rows, eps, out.data_ptr(), world, chunks,
+                                                        _stream(q)), "fp_qk_rmsnorm_rope_pack_bf16")
+    return out
+
+
 _ATTN_WS = {}
 
 

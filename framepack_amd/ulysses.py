@@ -61,14 +61,16 @@ def pick_chunks(n_total: int, heads_local: int, cus: int = 256) -> int:
 
 def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total: int, heads: int, head_dim: int,
                       attn_fn: Callable, group=None, out: Optional[torch.Tensor] = None,
-                      chunks: Optional[int] = None) -> torch.Tensor:
+                      chunks: Optional[int] = None, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q, k, v: [n, heads*head_dim] views (row-strided ok) holding this rank's run of the packed sequence (row_shard;
     padding rows included).  n_total = S, the valid rows over all ranks.  Returns / fills `out` (same shape; may be q)
     with the attention output of the local rows for all heads (padding rows: zeros).
 
     attn_fn(q, k, v, heads_local, out) -> out   over [S, heads_local*head_dim] views.
     chunks: head chunks exchanged and attended one after the other so that communication overlaps attention
-    (default: `pick_chunks`)."""
+    (default: `pick_chunks`).
+    packed: the send buffer [chunks, world, n, 3 * hc * head_dim] already filled by the producer of q | k | v
+    (ops.qk_rmsnorm_rope_pack: the RMSNorm/RoPE kernel writes it directly); q, k, v are then only read for their shape."""
     world = dist.get_world_size(group)
     if heads % world != 0:
         raise ValueError(f"{heads} heads do not divide over {world} ranks")
@@ -87,7 +89,12 @@ def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total
 
     # ---- pack: [n, P, chunk, (q|k|v), hwc] -> [chunk, P, n, 3*hwc]: per chunk one contiguous slice per peer; what a
     #      peer receives is the packed sequence in order (rank order = sequence order)
-    send = torch.stack([t.reshape(n, world, chunks, hwc) for t in (q, k, v)], dim=3).permute(2, 1, 0, 3, 4).contiguous()
+    if packed is not None:
+        if tuple(packed.shape) != (chunks, world, n, 3 * hwc) or not packed.is_contiguous():
+            raise ValueError(f"packed send buffer {tuple(packed.shape)} does not match {(chunks, world, n, 3 * hwc)}")
+        send = packed
+    else:
+        send = torch.stack([t.reshape(n, world, chunks, hwc) for t in (q, k, v)], dim=3).permute(2, 1, 0, 3, 4).contiguous()
     joints = [torch.empty((world * n, 3 * hwc), dtype=dt, device=dev) for _ in range(chunks)]
     fwd = [_all_to_all(joints[c], send[c].view(world * n, 3 * hwc), group, async_op=chunks > 1) for c in range(chunks)]
 

@@ -86,6 +86,15 @@ int fp_qk_rmsnorm_rope_bf16(void* q, void* k, int64_t row_stride, int rows, int 
                             const void* wq, const void* wk, const void* wq_txt, const void* wk_txt,
                             const float* rope, int rope_rows, float eps, void* stream);
 
+/* K2 for Ulysses sequence parallelism (no reference counterpart: the reference is single-GPU): the same arithmetic
+ * with q, k, v READ-ONLY and the results - v copied unchanged - written into `pack`, the send buffer of the head
+ * exchange: bf16 [chunks][world][rows][3][hc*128] with hc = heads / world / chunks; head h goes to peer h / (heads /
+ * world), chunk (h % (heads / world)) / hc.  One pass instead of K2 plus a packing copy of q|k|v. */
+int fp_qk_rmsnorm_rope_pack_bf16(const void* q, const void* k, const void* v, int64_t row_stride, int rows, int heads,
+                                 int head_dim, const void* wq, const void* wk, const void* wq_txt, const void* wk_txt,
+                                 const float* rope, int rope_rows, float eps, void* pack, int world, int chunks,
+                                 void* stream);
+
 /* K3  y = LayerNorm(x; no affine, eps) * (1 + scale) + shift,  x,y: [rows, cols], scale,shift: [cols].
  * Replaces diffusers_helper/dit_common.py:9-10 + hunyuan_video_packed.py:453, 476, 502, 642-643.
  * cols <= 4096. */

@@ -88,6 +88,31 @@ def test_qk_rmsnorm_rope(rows, rope_rows, heads, two_w):
     assert torch.equal(bd[:, 2 * d:].cpu(), buf[:, 2 * d:])     # v and pad untouched
 
 
+@pytest.mark.parametrize("rows,rope_rows,heads,world,chunks", [(37, 20, 4, 2, 2), (300, 300, 24, 4, 2), (65, 0, 24, 8, 1),
+                                                              (10, 7, 6, 1, 3)])
+def test_qk_rmsnorm_rope_into_the_exchange_send_buffer(rows, rope_rows, heads, world, chunks):
+    """The sequence-parallel form of K2: q, k, v stay as they are, and the send buffer of the head exchange holds
+    exactly what the in-place kernel computes (and v), laid out [chunk][peer][row][q|k|v][heads per chunk]."""
+    d = heads * 128
+    buf = randn(rows, 3 * d + 64, seed=17)
+    wq, wk = 1 + 0.1 * randn(128, seed=8), 1 + 0.1 * randn(128, seed=9)
+    wq2, wk2 = 1 + 0.1 * randn(128, seed=10), 1 + 0.1 * randn(128, seed=11)
+    g = torch.Generator("cpu").manual_seed(12)
+    ang = torch.rand(max(rope_rows, 1), 128, generator=g) * 6.28
+    rope = torch.cat([ang.cos(), ang.sin()], dim=-1).contiguous().to(DEV)
+    w = [x.to(DEV) for x in (wq, wk, wq2, wk2)]
+    raw = buf.to(DEV)
+    packed = ops.qk_rmsnorm_rope_pack(raw[:, :d], raw[:, d:2 * d], raw[:, 2 * d:3 * d], w[0], w[1], rope, rope_rows, heads,
+                                      world, chunks, wq_txt=w[2], wk_txt=w[3])
+    assert torch.equal(raw.cpu(), buf)                                   # inputs untouched
+    done = buf.to(DEV)
+    ops.qk_rmsnorm_rope_(done[:, :d], done[:, d:2 * d], w[0], w[1], rope, rope_rows, heads, wq_txt=w[2], wk_txt=w[3])
+    hwc = heads // world // chunks * 128
+    want = torch.stack([done[:, i * d:(i + 1) * d].reshape(rows, world, chunks, hwc) for i in range(3)], dim=3) \
+        .permute(2, 1, 0, 3, 4).reshape(chunks, world, rows, 3 * hwc)
+    assert tuple(packed.shape) == (chunks, world, rows, 3 * hwc) and torch.equal(packed, want)
+
+
 # ------------------------------------------------------------------ K7 / K10
 @pytest.mark.parametrize("n_in,n_out,silu", [(256, 1536, True), (3072, 18432, True), (3072, 100, False), (4096, 7, True)])
 def test_silu_gemv(n_in, n_out, silu):

@@ -55,17 +55,25 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     h = 24 // P
     q, k, v = rnd(S, h * 128), rnd(S, h * 128), rnd(S, h * 128)
     t["attention x60"] = 60 * timed(lambda: ops.attention(q, k, v, h), n=4)
-    if P > 1:
+    ql, kl, vl = o9[:, :3072], o9[:, 3072:6144], o9[:, 6144:]                # the q|k|v GEMM's output, row stride 9216
+    wn = rnd(128)
+    rope = torch.rand(n, 256, device=dev)
+    info = ""
+    if P == 1:
+        t["K2 x60"] = 60 * timed(lambda: ops.qk_rmsnorm_rope_(ql, kl, wn, wn, rope, n, 24))
+    else:
         from framepack_amd.ulysses import pick_chunks
         ch = pick_chunks(S, h)
         hwc = h // ch * 128
-        ql, kl, vl = o9[:, :3072], o9[:, 3072:6144], o9[:, 6144:]            # the q|k|v GEMM's output, row stride 9216
-        t[f"pack x60 ({ch} chunks)"] = 60 * timed(lambda: torch.stack(
-            [x.reshape(n, P, ch, hwc) for x in (ql, kl, vl)], dim=3).permute(2, 1, 0, 3, 4).contiguous())
+        t[f"K2 into the send buffer x60 ({ch} chunks)"] = 60 * timed(
+            lambda: ops.qk_rmsnorm_rope_pack(ql, kl, vl, wn, wn, rope, n, 24, P, ch))
         recv = rnd(P, n, hwc)
         t["unpack x60"] = 60 * timed(lambda: [o3.unflatten(1, (P, ch, hwc))[:, :, c].copy_(recv.permute(1, 0, 2))
                                               for c in range(ch)])
+        old_way = 60 * (timed(lambda: ops.qk_rmsnorm_rope_(ql, kl, wn, wn, rope, n, 24)) + timed(lambda: torch.stack(
+            [x.reshape(n, P, ch, hwc) for x in (ql, kl, vl)], dim=3).permute(2, 1, 0, 3, 4).contiguous()))
+        info = f" (K2 in place + a packing pass, replaced: {old_way:.1f})"
     tot = sum(t.values())
     base = base or tot * P
     print(f"P={P} rows/rank {n} heads/rank {h}: " + " | ".join(f"{k} {v:.1f}" for k, v in t.items()) +
-          f" | total {tot:.1f} ms = {base / P / tot * 100:.0f} % of ideal", flush=True)
+          f" | total {tot:.1f} ms = {base / P / tot * 100:.0f} % of ideal{info}", flush=True)
