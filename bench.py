@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--fp8", action="store_true",
                     help="block linears and attention on the fp8 MFMA (e4m3 operands: NOT the bf16 headline configuration)")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use cuda:0 and exchange over gloo (RCCL refuses two ranks on one device): "
+                         "runs the multi-rank code path on a one-GPU box; the number it prints is NOT a measurement")
     return ap.parse_args()
 
 
@@ -117,11 +120,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from framepack_amd import ops, sampler, synthetic
     from framepack_amd.model import HunyuanVideoTransformer3DModelPacked
@@ -226,7 +234,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": False,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "fp8-e4m3 block linears and attention (opt-in, outside the 1e-2 parity bar)" if args.fp8 else "bf16",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if args.rehearse_one_gpu else ""),
             "config": {"workload": workload, "packed_tokens": S, "image_tokens": Si, "text_tokens": St,
                        "teacache": False, "parallelism": "single GPU" if world == 1 else f"ulysses-sp{world}"},
             "model_tflops_per_step": round((24 * 3072 ** 2 * S + 4 * S * S * 3072) * 60 / 1e12, 1) if args.config == "13b" else None,
