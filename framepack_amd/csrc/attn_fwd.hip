@@ -3,18 +3,22 @@
 // Replaces ref diffusers_helper/models/hunyuan_video_packed.py:89-112 (attn_varlen_func: the SDPA
 // branch :97 is the parity target; the sageattention / flash / xformers dispatch is gone).
 //
-// Structure (one workgroup = 8 waves = 256 query rows of one head; each wave owns 32 query rows):
-//   * Q fragments stay in registers for the whole KV sweep (32 VGPRs).
-//   * K and V tiles of 64 keys are staged global -> registers -> LDS, double buffered.
+// Structure common to both sweeps in this file (one workgroup = 4 waves = 256 query rows of one head, one wave per SIMD,
+// each wave owning 64 query rows as two 32-row blocks):
+//   * Q stays on chip for the whole KV sweep (second generation: VGPR fragments; third: pre-scaled, in AGPRs).
+//   * K and V tiles of 64 keys come by LDS-DMA (global_load_lds) into rings of 16 KiB slots.
 //   * S^T = K.Q^T (operands swapped): the 32x32 accumulator then has the QUERY on the lane and 16 keys in
-//     registers, so the online softmax is lane-local (one cross-half exchange per tile for the max).
-//   * O^T = V^T.P^T: the S^T accumulators, converted to bf16 in place, ARE the B operand (no LDS round
-//     trip); V^T fragments come from LDS through ds_read_b64_tr_b16 (hardware transpose), with the k
-//     index permuted to match the accumulator's register->key map.
+//     registers, so the online softmax is lane-local (one cross-half exchange when a row max is needed).
+//   * O^T = V^T.P^T: the S^T accumulators, converted to bf16, ARE the B operand (no LDS round trip); V^T fragments
+//     come from LDS through ds_read_b64_tr_b16 (hardware transpose), with the k index permuted to match the
+//     accumulator's register->key map.
 //   * K image: [key][256 B] with the 16-B chunk index XOR (key & 15)  -> conflict-free ds_read_b128.
 //     V image: [d/32][key][64 B]                                      -> conflict-free tr reads.
 //   * Tails: rows are clamped on load, scores of keys past the segment end are masked to -inf in the
 //     last tile only, query rows past the end are not stored.  Nothing is padded in memory.
+//   * The items of the last, partial round of workgroups are cut into KV ranges (fp32 partials in a workspace) and
+//     merged by attn_combine_kernel.
+// attn_w64_kernel (second generation, variant 1) and attn_v3_kernel (third, default) are described at their definitions.
 #include <atomic>
 #include <mutex>
 #include <type_traits>
