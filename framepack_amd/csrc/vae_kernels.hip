@@ -64,13 +64,14 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
     // centre taps are packed t << 22 | h << 11 | w in gemm_w4.h, in tap coordinates (strided: twice the output's)
     FP_REQUIRE((cg.To << cg.dt) < 1024 && (cg.Ho << cg.dh) < 2048 && (cg.Wo << cg.dw) < 2048);
     const int M = (int)M64, N = Cout, K = 27 * cg.Cin;
-    // the 4-wave kernel's gather: Cin a power of two (voxel steps become shifts), 24-bit multiplies of the plane and
-    // row pitch in voxels, sources addressed in 16-byte units from the volume's start
-    FP_REQUIRE((cg.Cin & (cg.Cin - 1)) == 0 && (int64_t)cg.Hi * cg.Wi < (1 << 23) &&
-               (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin * 2 / 16 < (1ll << 32));
-    FP_REQUIRE(cg.lcin == __builtin_ctz((unsigned)cg.Cin));
     FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + 31) / 32) < (1ll << 31));
-    const bool wide = ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
+    // the 4-wave kernel's gather needs Cin to be a power of two (voxel steps become shifts), 24-bit multiplies of the
+    // plane and row pitch in voxels, and sources addressable in 16-byte units from the volume's start; anything else
+    // (and outputs aligned to 8 bytes only) runs on the 8-wave kernel, which computes every source from coordinates
+    const bool pow2 = (cg.Cin & (cg.Cin - 1)) == 0 && cg.lcin == __builtin_ctz((unsigned)cg.Cin) &&
+                      (int64_t)cg.Hi * cg.Wi < (1 << 23) &&
+                      (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin * 2 / 16 < (1ll << 32);
+    const bool wide = pow2 && ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
     // Cout <= 128 / <= 32 (the last up block and conv_out): the narrow tiles of gemm_w4.h
     if (wide && N <= 32 && !resid)
         return launch_w4<f16, 0, 1, f16, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);

@@ -61,6 +61,8 @@ def ref_conv(x_cl, w, b, up=(1, 1, 1), resid=None):
     (5, 40, 40, 128, 128, (1, 1, 1), True),       # several M tiles
     (5, 32, 48, 64, 128, (1, 1, 1), True),        # a frame = 6 whole tiles
     (3, 16, 16, 64, 256, (2, 2, 2), False),       # whole tiles per frame, with upsampling
+    (3, 9, 11, 192, 72, (1, 1, 1), True),         # Cin not a power of two: the 8-wave kernel's coordinate gather
+    (2, 6, 5, 192, 136, (2, 2, 2), False),        # the same with upsampling
 ])
 def test_conv3d_causal(T, H, W, cin, cout, up, with_res):
     x = rand(T, H, W, cin, seed=1)
@@ -81,6 +83,7 @@ def test_conv3d_causal(T, H, W, cin, cout, up, with_res):
     (4, 9, 7, 128, 64, (2, 2, 2)),                # even T (4 -> 2) and odd H, W (9 -> 5, 7 -> 4): upper clamps
     (3, 6, 6, 64, 128, (2, 1, 1)),                # temporal stride only
     (3, 40, 40, 64, 256, (1, 2, 2)),              # several M tiles
+    (4, 9, 7, 192, 64, (2, 2, 2)),                # Cin not a power of two
 ])
 def test_conv3d_causal_strided(T, H, W, cin, cout, stride):
     x = rand(T, H, W, cin, seed=1)
