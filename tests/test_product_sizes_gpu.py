@@ -32,12 +32,14 @@ def psnr(a, b, peak=2.0):
 
 
 # ------------------------------------------------------------------ (a) + (d): 13B-width blocks, full S, pad > 0
-@pytest.mark.parametrize("height,width,latent_padding", [(640, 640, 0), (320, 320, 3)],
-                         ids=["config2_S19385", "config4_pad3_indices"])
+@pytest.mark.parametrize("height,width,latent_padding", [(640, 640, 0), (320, 320, 3), (640, 608, 1)],
+                         ids=["config2_S19385", "config4_pad3_indices", "real_square_bucket_640x608"])
 def test_13b_width_blocks_at_product_length(height, width, latent_padding):
     """1 double + 1 single block at 13B width (24 heads x 128, mlp 12288) on the BASELINE config-2 section
     (640x640x33f, 256 text tokens: S = 19 385), per-block rel-L2 <= 1e-2 against the fp32 oracle; and the config-4
-    index layout (latent_padding 3: every index after clean_pre shifted by 27, ref worker.py:463-465)."""
+    index layout (latent_padding 3: every index after clean_pre shifted by 27, ref worker.py:463-465); and the bucket
+    a square input really gets (ref bucket_tools.py: (640, 608) - post-patch width 38, so the 4x stream is
+    replicate-padded to a multiple of its kernel, ref hunyuan_video_packed.py:45-51) at 13B width."""
     cfg_kw = dict(synthetic.CONFIG_13B, num_layers=1, num_single_layers=1)
     m = HunyuanVideoTransformer3DModelPacked(**cfg_kw).to(BF)
     synthetic.init_synthetic_(dict(m.state_dict()), seed=1)
