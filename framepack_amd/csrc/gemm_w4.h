@@ -192,9 +192,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             asm volatile("" : "+v"(pa[h][j]));      // keeps "base + lane offset" from being hoisted as a 64-bit register pair
             return reinterpret_cast<const T*>(abase + koff * (int64_t)sizeof(T) + pa[h][j]);
         } else {
-            const int k0 = t * BKE;
-            const int tap = k0 >> cg.lcin, c0 = k0 & (cg.Cin - 1);                   // (uniform)
-            const int it = tap / 9, ih = (tap / 3) % 3, iw = tap % 3;
+            const unsigned k0 = (unsigned)t * BKE;
+            const unsigned tap = k0 >> cg.lcin, c0 = k0 & (unsigned)(cg.Cin - 1);    // (uniform; tap < 27)
+            const unsigned t3 = (tap * 11u) >> 5, it = (tap * 57u) >> 9;             // tap / 3, tap / 9
+            const unsigned ih = t3 - 3u * it, iw = tap - 3u * t3;
             const int code = (int)ccode[h][j];
             const int dT = __builtin_amdgcn_sbfe(code, 2 * it, 2), dH = __builtin_amdgcn_sbfe(code, 6 + 2 * ih, 2),
                       dW = __builtin_amdgcn_sbfe(code, 12 + 2 * iw, 2);
