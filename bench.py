@@ -19,6 +19,7 @@ Also printed on the same JSON line:
   roofline     - the dominant kernel (K1 flash attention): algorithmic FLOPs per launch (4 * S^2 * heads * 128,
                  per rank) / its average duration measured live with events on its own stream over the timed
                  region, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  short_prompt - (N == 1, informational) ms per step of the same section with a 64-token prompt (S = 19 193).
   vae_decode   - (N == 1, informational; not part of `value`) the causal-3D VAE decode of the section's 9 latent
                  frames to 33 frames at 640x640 (framepack_amd/vae.py, random-init fp16 weights), ms per decode.
   cpu_baseline - the CPU oracle (kind "port") timed on this box's host cores on a bounded sample
@@ -166,7 +167,7 @@ def main():
     k_model = sampler.fm_wrapper(model)
     mu = sampler.calculate_flux_mu(frames_latent * (height // 8) * (width // 8) // 4, exp_max=7.0)
 
-    def run_steps(n):
+    def run_steps(n, extra=extra):
         # the first n+1 entries of the real 25-step schedule: n model calls (UniPC never reads the last sigma)
         out = None
         while n > 0:
@@ -193,6 +194,24 @@ def main():
         events, ops.ATTN_EVENTS = ops.ATTN_EVENTS, None
         if not bool(torch.isfinite(out).all()):
             raise SystemExit("bench: the timed steps produced non-finite latents - the number would be meaningless")
+
+    # informational ("worst case S = 19 385; also report n = 64"): the same section with a 64-token prompt
+    short_prompt = None
+    if world == 1 and args.config == "13b" and args.n_text != 64:
+        kw64 = synthetic.make_inputs(seed=31337, frames_latent=frames_latent, height=height, width=width, n_text=64, dtype=bf)
+        for k in ("hidden_states", "timestep"):
+            kw64.pop(k)
+        pos64 = {k: (v.to(dev) if torch.is_tensor(v) and v.dtype in (bf, torch.bool) else v) for k, v in kw64.items()}
+        pos64["guidance"] = guidance
+        extra64 = dict(extra, positive=pos64)
+        with torch.inference_mode():
+            run_steps(1, extra64)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(5, extra64)
+            torch.cuda.synchronize()
+        short_prompt = {"n_text": 64, "packed_tokens": synthetic.packed_lengths(frames_latent, height, width, 64)[2],
+                        "ms_per_step": round((time.perf_counter() - t1) / 5 * 1e3, 3), "steps": 5}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -243,6 +262,8 @@ def main():
         if args.config == "13b":
             fl = (24 * 3072 ** 2 * S + 4 * S * S * 3072) * 60
             line["model_mfma_frac"] = round(fl / (ms_per_step / 1e3) / (MFMA_BF16_PEAK * world), 4)
+        if short_prompt is not None:
+            line["short_prompt"] = short_prompt
         if world == 1 and args.config == "13b":
             line["vae_decode"] = vae_decode_ms(dev, frames_latent, height // 8, width // 8)
         if world == 1 and not args.no_cpu_baseline and args.config == "13b":
