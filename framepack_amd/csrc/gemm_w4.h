@@ -40,8 +40,11 @@ __device__ __forceinline__ void reserve_agprs() {
 }
 
 // a[IDX:IDX+3] (+)= w . a   (operands swapped as in gemm_pipeline.h: the token row ends up on the lane)
-template <typename T, int IDX, bool ZERO_C>
+// LGKM >= 0: at most LGKM LDS reads may still be in flight when the MFMA issues (the 16-bit main loop reads its
+// fragments with inline asm, invisible to the compiler's wait-count bookkeeping - see rd_a)
+template <typename T, int IDX, bool ZERO_C, int LGKM = -1>
 __device__ __forceinline__ void mfma_acc(const i32x4& w, const i32x4& a) {
+    if constexpr (LGKM >= 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LGKM));
     if constexpr (std::is_same<T, bf16>::value) {
         if constexpr (ZERO_C)
             asm volatile("v_mfma_f32_16x16x32_bf16 a[%0:%1], %2, %3, 0" ::"n"(IDX), "n"(IDX + 3), "v"(w), "v"(a));
@@ -70,6 +73,37 @@ template <int IDX> __device__ __forceinline__ f32x4 acc_read() {
                  : "n"(IDX), "n"(IDX + 1), "n"(IDX + 2), "n"(IDX + 3));
     return f32x4{r0, r1, r2, r3};
 }
+
+template <int OFF> __device__ __forceinline__ void lds_read_b128(i32x4& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+// LDS reads that may still be in flight when group g (0..5) of phase P issues its first MFMA, from the order in which
+// the 16-bit loop issues them (LDS reads return in order).  P0: [W(ks 0, ni < NT), A0, A1] behind the barrier, then
+// behind group j's MFMAs 0 / 1 / 2: A(j+2), W(ks 1, 2j), W(ks 1, 2j+1) (the W reads for j < 4 and ni < NT only: a
+// fragment no MFMA uses is never read - its register would be handed out again while the read is in flight).
+// Group g needs A(g) and W(ks g/4).  P1: [A0, A1], then A(j+2) behind group j's first MFMA; W is in registers.
+constexpr int lgkm_before(int P, int g, int NT) {
+    if (P == 1) return 1;
+    int issued = 0, idx_a[8] = {}, last_w1 = -1;
+    issued += NT < 8 ? NT : 8;                  // W(ks 0)
+    idx_a[0] = issued++;
+    idx_a[1] = issued++;
+    for (int j = 0; j < g; ++j) {               // what groups 0 .. g-1 issue
+        idx_a[j + 2] = issued++;
+        if (j < 4) {
+            if (2 * j < NT) last_w1 = issued++;
+            if (2 * j + 1 < NT) last_w1 = issued++;
+        }
+    }
+    int need = idx_a[g];
+    if (g >= 4 && last_w1 > need) need = last_w1;
+    return issued - (need + 1);
+}
+static_assert(lgkm_before(0, 0, 8) == 1 && lgkm_before(0, 1, 8) == 3 && lgkm_before(0, 2, 8) == 5 &&
+              lgkm_before(0, 3, 8) == 5 && lgkm_before(0, 4, 8) == 0 && lgkm_before(0, 5, 8) == 1, "wait counts, NT = 8");
+static_assert(lgkm_before(0, 0, 4) == 1 && lgkm_before(0, 1, 4) == 3 && lgkm_before(0, 2, 4) == 5 &&
+              lgkm_before(0, 3, 4) == 3 && lgkm_before(0, 4, 4) == 1 && lgkm_before(0, 5, 4) == 1, "wait counts, NT = 4");
 
 // NT = 16-column tiles per wave (8 | 4 | 1): the workgroup's tile is 256 x (32 NT).  Narrow outputs (the VAE's
 // Cout = 128 and Cout = 3 layers, N <= 128 / N <= 32) take NT = 4 / 1: the two wave columns then share the real
@@ -272,16 +306,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         mfma8_acc<((P * 4 + MI) * 8 + NI) * 4, ZC>(w8[KS == 1 ? (int)NI : 0], a8[KS == 1 ? (int)P : 0][MI]);
     };
 
+    // The 16-bit loop's fragment reads are inline asm, and every wait for them is written out (lgkm_before below).
+    // As C++ loads they were waited for by the compiler, which does not see the loop's own `s_waitcnt` in front of
+    // the barrier: it still held the previous phase's last two reads for pending, and drained the counter - with the
+    // new phase's first ten reads just issued - in front of the held-back MFMAs that were meant to cover their latency.
+    // (The dynamic LDS segment starts at address 0: the kernel has no static LDS.)
     auto rd_a = [&](auto BUF, auto P, auto G) __attribute__((always_inline)) {
-        af[G & 3] = *reinterpret_cast<const frag_t*>(smem + a_rd[G >> 2] + BUF * OP_BYTES + (P * 64 + (G & 3) * 16) * 128);
+        constexpr int off = BUF * OP_BYTES + (P * 64 + (G & 3) * 16) * 128;
+        lds_read_b128<off>(af[G & 3], a_rd[G >> 2]);
     };
     auto rd_w = [&](auto BUF, auto KS_, auto NI) __attribute__((always_inline)) {
-        wf[KS_][NI] = *reinterpret_cast<const frag_t*>(smem + w_rd[KS_] + BUF * OP_BYTES + (NI * 16) * 128);
+        constexpr int off = BUF * OP_BYTES + (NI * 16) * 128;
+        if constexpr (NI < NT) lds_read_b128<off>(wf[KS_][NI], w_rd[KS_]);
     };
-    // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0)
-    auto mfma1 = [&](auto P, auto G, auto NI, auto ZC) __attribute__((always_inline)) {
+    // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0); LGKM: wait in front (-1: none)
+    auto mfma1 = [&](auto P, auto G, auto NI, auto ZC, auto LGKM) __attribute__((always_inline)) {
         constexpr int MI = P * 4 + (G & 3);
-        if constexpr (NI < NT) mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0)>(wf[G >> 2][NI], af[G & 3]);
+        if constexpr (NI < NT) mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0), LGKM>(wf[G >> 2][NI], af[G & 3]);
     };
     // what is issued behind MFMA k of group g: at most one LDS read or one LDS-DMA per MFMA gap.
     //   P0(t) issues A-h1(t+1);  P1(t) issues A-h0(t+2) and W(t+2)  (W's fragments sit in registers after P0).
@@ -351,14 +392,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             rd_a(BUF, P, ic<0>{});
             rd_a(BUF, P, ic<1>{});
             fence();
-            if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind
-                static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}); });
-                static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}); });
+            if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind (fragments long landed)
+                static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}, ic<-1>{}); });
+                static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<7>{}, ni, ic<0>{}, ic<-1>{}); });
             }
             fence();
             static_for<6>([&](auto g) __attribute__((always_inline)) {
                 static_for<8>([&](auto k) __attribute__((always_inline)) {
-                    mfma1(P, g, k, ZC);
+                    mfma1(P, g, k, ZC, ic<(k == 0 ? lgkm_before(P, g, NT) : -1)>{});
                     fence();
                     slot(BUF, P, t, g, k);
                     fence();
@@ -520,8 +561,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if (nk == 1) tail(ic<1>{});          // the only K tile's held-back tiles start from C = 0
             else tail(ic<0>{});
         } else {
-            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}); });
-            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}); });
+            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<6>{}, ni, ic<0>{}, ic<-1>{}); });
+            static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1>{}, ic<7>{}, ni, ic<0>{}, ic<-1>{}); });
         }
         fence();
         // every wave is done with the LDS (and the clamped tail loads have landed): the next tile's first loads

@@ -243,3 +243,55 @@ def test_attention_kernels_keep_compiler_out_of_the_agprs(tmp_path):
         assert int(re.search(re.escape(name) + r"\.num_vgpr, (\d+)", text).group(1)) <= 256
         assert int(re.search(re.escape(name) + r"\.private_seg_size, (\d+)", text).group(1)) == 0
     assert seen == 2
+
+
+def test_gemm_fragment_reads_all_feed_an_mfma(tmp_path):
+    """The 16-bit GEMM / convolution main loop reads its MFMA fragments with inline asm (the compiler's wait counts do
+    not see the loop's own s_waitcnt, gemm_w4.h).  The compiler takes an asm output for written at once: a fragment that
+    no MFMA reads is dead to it, its register is handed out again, and the LDS data that lands later overwrites the new
+    owner (seen once: the narrow-tile kernels read W fragments they never multiply, addresses were overwritten, the GPU
+    faulted).  Compile to assembly and check, per 4-wave kernel: every inline-asm ds_read_b128 destination is read by
+    an MFMA before anything writes that register again."""
+    import re
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("needs hipcc")
+    seen = 0
+    for fname in ("gemm_bf16.hip", "vae_kernels.hip"):
+        src = os.path.join(ROOT, "framepack_amd", "csrc", fname)
+        out = tmp_path / (fname + ".s")
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(out)],
+                       check=True, capture_output=True)
+        text = out.read_text()
+        for m in re.finditer(r"^(_ZN7fp_gemm14gemm_w4_kernel\S*):[^\n]*\n(.*?)^\s*\.amdhsa_kernel \1", text, re.S | re.M):
+            name, body = m.group(1), m.group(2)
+            seen += 1
+            pending = {}                      # first register of an asm fragment read -> not yet used by an MFMA
+            in_asm = False
+            for line in body.splitlines():
+                t = line.strip()
+                if "#ASMSTART" in t:
+                    in_asm = True
+                    continue
+                if "#ASMEND" in t:
+                    in_asm = False
+                    continue
+                if t.startswith("v_mfma"):
+                    for r in re.findall(r"v\[(\d+):\d+\]", t):
+                        pending.pop(int(r), None)
+                    continue
+                rd = re.match(r"ds_read_b128 v\[(\d+):(\d+)\]", t) if in_asm else None
+                if rd:
+                    lo = int(rd.group(1))
+                    assert lo not in pending, (name, "a fragment read is overwritten before any MFMA used it", t)
+                    pending[lo] = t
+                elif pending and not in_asm:
+                    # any compiler instruction that WRITES a register of a pending fragment
+                    w = re.match(r"(?:v_|ds_read|global_load|buffer_load)\S*\s+v(?:\[(\d+):(\d+)\]|(\d+))", t)
+                    if w and not t.startswith(("v_cmp", "v_mfma")):
+                        lo = int(w.group(1) or w.group(3))
+                        hi = int(w.group(2) or w.group(3))
+                        for p in list(pending):
+                            assert not (lo <= p + 3 and hi >= p), (name, "register of an in-flight fragment read reused", t)
+    assert seen >= 12
