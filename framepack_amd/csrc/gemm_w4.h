@@ -83,27 +83,33 @@ template <int OFF> __device__ __forceinline__ void lds_read_b128(i32x4& dst, uns
 // behind group j's MFMAs 0 / 1 / 2: A(j+2), W(ks 1, 2j), W(ks 1, 2j+1) (the W reads for j < 4 and ni < NT only: a
 // fragment no MFMA uses is never read - its register would be handed out again while the read is in flight).
 // Group g needs A(g) and W(ks g/4).  P1: [A0, A1], then A(j+2) behind group j's first MFMA; W is in registers.
+#ifndef FP_A_AHEAD
+#define FP_A_AHEAD 2
+#endif
+constexpr int A_AHEAD = FP_A_AHEAD;             // an A fragment is read this many groups (of 8 MFMAs) before its own
+constexpr int A_RING = A_AHEAD <= 2 ? 4 : 8;
 constexpr int lgkm_before(int P, int g, int NT) {
-    if (P == 1) return 1;
-    int issued = 0, idx_a[8] = {}, last_w1 = -1;
-    issued += NT < 8 ? NT : 8;                  // W(ks 0)
-    idx_a[0] = issued++;
-    idx_a[1] = issued++;
+    int issued = 0, idx_a[16] = {}, last_w1 = -1;
+    if (P == 0) issued += NT < 8 ? NT : 8;      // W(ks 0)
+    for (int i = 0; i < A_AHEAD; ++i) idx_a[i] = issued++;
     for (int j = 0; j < g; ++j) {               // what groups 0 .. g-1 issue
-        idx_a[j + 2] = issued++;
-        if (j < 4) {
+        if (j + A_AHEAD < 8) idx_a[j + A_AHEAD] = issued++;
+        if (P == 0 && j < 4) {
             if (2 * j < NT) last_w1 = issued++;
             if (2 * j + 1 < NT) last_w1 = issued++;
         }
     }
     int need = idx_a[g];
-    if (g >= 4 && last_w1 > need) need = last_w1;
+    if (P == 0 && g >= 4 && last_w1 > need) need = last_w1;
     return issued - (need + 1);
 }
+#if FP_A_AHEAD == 2
 static_assert(lgkm_before(0, 0, 8) == 1 && lgkm_before(0, 1, 8) == 3 && lgkm_before(0, 2, 8) == 5 &&
               lgkm_before(0, 3, 8) == 5 && lgkm_before(0, 4, 8) == 0 && lgkm_before(0, 5, 8) == 1, "wait counts, NT = 8");
 static_assert(lgkm_before(0, 0, 4) == 1 && lgkm_before(0, 1, 4) == 3 && lgkm_before(0, 2, 4) == 5 &&
               lgkm_before(0, 3, 4) == 3 && lgkm_before(0, 4, 4) == 1 && lgkm_before(0, 5, 4) == 1, "wait counts, NT = 4");
+static_assert(lgkm_before(1, 0, 8) == 1 && lgkm_before(1, 3, 8) == 1 && lgkm_before(1, 5, 4) == 1, "wait counts, phase 1");
+#endif
 
 // NT = 16-column tiles per wave (8 | 4 | 1): the workgroup's tile is 256 x (32 NT).  Narrow outputs (the VAE's
 // Cout = 128 and Cout = 3 layers, N <= 128 / N <= 32) take NT = 4 / 1: the two wave columns then share the real
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
 
     // W fragments of the current K tile: [ks][ni].  A fragments: a ring of 4 groups; group g of a phase =
     // (ks = g >> 2, mi = 4 p + (g & 3)).
-    frag_t wf[KS == 2 ? 2 : 1][8], af[4];
+    frag_t wf[KS == 2 ? 2 : 1][8], af[A_RING];
     // fp8 (KS == 1): a tile's operand is the pair of 16-B reads side by side.  A fragments of BOTH phases' row halves
     // (the held-back MFMAs of a phase still read the previous half's), W fragments of the K tile.
     i32x8 a8[KS == 1 ? 2 : 1][4], w8[KS == 1 ? 8 : 1];
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // (The dynamic LDS segment starts at address 0: the kernel has no static LDS.)
     auto rd_a = [&](auto BUF, auto P, auto G) __attribute__((always_inline)) {
         constexpr int off = BUF * OP_BYTES + (P * 64 + (G & 3) * 16) * 128;
-        lds_read_b128<off>(af[G & 3], a_rd[G >> 2]);
+        lds_read_b128<off>(af[G & (A_RING - 1)], a_rd[G >> 2]);
     };
     auto rd_w = [&](auto BUF, auto KS_, auto NI) __attribute__((always_inline)) {
         constexpr int off = BUF * OP_BYTES + (NI * 16) * 128;
@@ -322,14 +328,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0); LGKM: wait in front (-1: none)
     auto mfma1 = [&](auto P, auto G, auto NI, auto ZC, auto LGKM) __attribute__((always_inline)) {
         constexpr int MI = P * 4 + (G & 3);
-        if constexpr (NI < NT) mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0), LGKM>(wf[G >> 2][NI], af[G & 3]);
+        if constexpr (NI < NT) mfma_acc<T, (MI * 8 + NI) * 4, (ZC && (G >> 2) == 0), LGKM>(wf[G >> 2][NI], af[G & (A_RING - 1)]);
     };
     // what is issued behind MFMA k of group g: at most one LDS read or one LDS-DMA per MFMA gap.
     //   P0(t) issues A-h1(t+1);  P1(t) issues A-h0(t+2) and W(t+2)  (W's fragments sit in registers after P0).
     auto slot = [&](auto BUF, auto P, int t, auto G, auto K_) __attribute__((always_inline)) {
         constexpr int g = G, k = K_;
         constexpr int g4 = g < 4 ? g : 0;
-        if constexpr (k == 0) rd_a(BUF, P, ic<g + 2>{});
+        if constexpr (k == 0 && g + A_AHEAD < 8) rd_a(BUF, P, ic<g + A_AHEAD>{});
         if constexpr (P == 0) {
             if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * g4>{});
             if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * g4 + 1>{});
@@ -389,8 +395,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else {
             if constexpr (P == 0) static_for<8>([&](auto ni) __attribute__((always_inline)) { rd_w(BUF, ic<0>{}, ni); });
-            rd_a(BUF, P, ic<0>{});
-            rd_a(BUF, P, ic<1>{});
+            static_for<A_AHEAD>([&](auto g) __attribute__((always_inline)) { rd_a(BUF, P, g); });
             fence();
             if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind (fragments long landed)
                 static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}, ic<-1>{}); });
