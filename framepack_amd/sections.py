@@ -42,14 +42,39 @@ def section_indices(latent_padding: int, latent_window_size: int, one_frame_infe
 
 
 def soft_append_bcthw(history: torch.Tensor, current: torch.Tensor, overlap: int = 0) -> torch.Tensor:
-    """ref diffusers_helper/utils.py:64-75: linear cross-fade of `overlap` frames between two clips."""
-    if overlap <= 0:
-        return torch.cat([history, current], dim=2)
-    assert history.shape[2] >= overlap, f"History length ({history.shape[2]}) must be >= overlap ({overlap})"
-    assert current.shape[2] >= overlap, f"Current length ({current.shape[2]}) must be >= overlap ({overlap})"
-    weights = torch.linspace(1, 0, overlap, dtype=history.dtype, device=history.device).view(1, 1, -1, 1, 1)
-    blended = weights * history[:, :, -overlap:] + (1 - weights) * current[:, :, :overlap]
-    return torch.cat([history[:, :, :-overlap], blended, current[:, :, overlap:]], dim=2).to(history)
+    """ref diffusers_helper/utils.py:64-75: `current` appended to `history` along T, the last `overlap` frames of the
+    one cross-faded linearly (weights 1 -> 0, ends included) into the first `overlap` frames of the other.  Written
+    into one output buffer; the blend keeps the reference's order of operations (w h + (1 - w) c in history's dtype)
+    so the frames are bit-identical (`tests/golden/utils.npz`)."""
+    th, tc = history.shape[2], current.shape[2]
+    ov = max(int(overlap), 0)
+    if ov:
+        assert th >= ov, f"History length ({th}) must be >= overlap ({ov})"
+        assert tc >= ov, f"Current length ({tc}) must be >= overlap ({ov})"
+    shape = list(history.shape)
+    shape[2] = th + tc - ov
+    out = torch.empty(shape, dtype=history.dtype, device=history.device)
+    out[:, :, :th - ov] = history[:, :, :th - ov]
+    out[:, :, th:] = current[:, :, ov:]
+    if ov:
+        w = torch.linspace(1, 0, ov, dtype=history.dtype, device=history.device).view(1, 1, ov, 1, 1)
+        out[:, :, th - ov:th] = w * history[:, :, th - ov:] + (1 - w) * current[:, :, :ov]
+    return out
+
+
+def crop_or_pad_yield_mask(x: torch.Tensor, length: int):
+    """ref diffusers_helper/utils.py:157-169 (the worker brings every prompt embedding to 512 rows with it,
+    worker.py:189-190, 392): x [B, F, C] -> ([B, length, C], bool mask [B, length]); rows past F are zeros with mask False,
+    a longer x is cut (a view, like the reference) and the mask is all True."""
+    B, F, C = x.shape
+    keep = min(F, length)
+    mask = torch.zeros((B, length), dtype=torch.bool, device=x.device)
+    mask[:, :keep] = True
+    if F >= length:
+        return x[:, :length, :], mask
+    y = x.new_zeros((B, length, C))
+    y[:, :F] = x
+    return y, mask
 
 
 def pick_ui_section(i_section: int, keys, total_sections: int):

@@ -12,6 +12,11 @@ What is pinned by what:
   * fp8.npz                  <- utils/fp8_optimization_utils.py (imports as is).
   * lora.npz                 <- utils/lora_utils.py (imports as is): the three LoRA layouts merged into seeded
                                  state dicts (inputs rebuilt in the test by tests/lora_cases.py).
+  * utils.npz                <- diffusers_helper/utils.py: soft_append_bcthw, crop_or_pad_yield_mask,
+                                 repeat_to_batch_size.  The module's top-level `import cv2` / `import torchvision` name
+                                 packages this image lacks; two EMPTY module objects stand in for them during the import
+                                 (none of the three functions touches either; the functions that do - mp4 / image I/O -
+                                 are out of scope and are not called).  Inputs rebuilt in the test from the same seeds.
 Inputs are regenerated in the tests from the same seeds (framepack_amd/synthetic.py,
 oracle.dit_oracle.synth_params); only outputs (sub-sampled where large) are stored.
 """
@@ -269,7 +274,40 @@ def gen_lora():
     print("lora.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- tensor helpers of the section loop
+def utils_cases():
+    """Seeded inputs shared with tests/test_sections_cpu.py (which imports this function's twin from
+    tests/utils_cases.py - kept there so the test does not import this generator)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import utils_cases as UC
+    return UC
+
+
+def gen_utils():
+    import types
+    for name in ("cv2", "torchvision"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    from diffusers_helper import utils as ref_utils
+    UC = utils_cases()
+    out = {}
+    for name, (h, c, ov) in UC.soft_append_cases().items():
+        out[f"soft_append/{name}"] = ref_utils.soft_append_bcthw(h, c, ov).float().numpy()
+    for name, (x, length) in UC.crop_or_pad_cases().items():
+        y, m = ref_utils.crop_or_pad_yield_mask(x, length)
+        out[f"crop_or_pad/{name}/y"] = y.float().numpy()
+        out[f"crop_or_pad/{name}/mask"] = m.numpy()
+    for name, (x, b) in UC.repeat_cases().items():
+        try:
+            out[f"repeat/{name}"] = ref_utils.repeat_to_batch_size(x, b).numpy()
+        except ValueError as e:
+            out[f"repeat/{name}/error"] = np.array([str(e)])
+    np.savez_compressed(os.path.join(HERE, "utils.npz"), **out)
+    print("utils.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    gen_utils()
     gen_rope()
     gen_sampler()
     gen_fp8()

@@ -120,3 +120,47 @@ def test_section_maps_are_keyed_by_ui_section_and_take_the_nearest_earlier_entry
     calls.clear()
     S.generate_sections(sample_fn, None, start, 32, 32, 3, section_latents={1: lat[2]})
     assert calls == [12.0, 12.0, -1.0]
+
+
+# ---- the tensor helpers either side of the section loop, pinned by the reference's own functions: tests/golden/utils.npz
+#      holds what diffusers_helper/utils.py returned for the seeded inputs of tests/utils_cases.py (make_golden.gen_utils)
+def _utils_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "utils.npz"))
+
+
+def test_soft_append_bit_identical_to_the_reference():
+    import utils_cases as UC
+    G = _utils_golden()
+    for name, (h, c, ov) in UC.soft_append_cases().items():
+        got = S.soft_append_bcthw(h, c, ov)
+        assert got.dtype == h.dtype, name
+        assert np.array_equal(got.float().numpy(), G[f"soft_append/{name}"]), name
+    with pytest.raises(AssertionError, match="History length"):
+        S.soft_append_bcthw(torch.zeros(1, 3, 2, 2, 2), torch.zeros(1, 3, 5, 2, 2), 3)
+    with pytest.raises(AssertionError, match="Current length"):
+        S.soft_append_bcthw(torch.zeros(1, 3, 5, 2, 2), torch.zeros(1, 3, 2, 2, 2), 3)
+
+
+def test_crop_or_pad_yield_mask_bit_identical_to_the_reference():
+    import utils_cases as UC
+    G = _utils_golden()
+    for name, (x, length) in UC.crop_or_pad_cases().items():
+        y, m = S.crop_or_pad_yield_mask(x, length)
+        assert y.dtype == x.dtype and m.dtype == torch.bool, name
+        assert np.array_equal(y.float().numpy(), G[f"crop_or_pad/{name}/y"]), name
+        assert np.array_equal(m.numpy(), G[f"crop_or_pad/{name}/mask"]), name
+
+
+def test_repeat_to_batch_size_bit_identical_to_the_reference():
+    import utils_cases as UC
+    from framepack_amd.sampler import repeat_to_batch_size
+    G = _utils_golden()
+    for name, (x, b) in UC.repeat_cases().items():
+        if f"repeat/{name}/error" in G.files:
+            with pytest.raises(ValueError) as e:
+                repeat_to_batch_size(x, b)
+            assert str(e.value) == str(G[f"repeat/{name}/error"][0]), name
+        else:
+            assert np.array_equal(repeat_to_batch_size(x, b).numpy(), G[f"repeat/{name}"]), name
+    assert repeat_to_batch_size(None, 3) is None

@@ -1,0 +1,46 @@
+"""Seeded inputs for the tensor helpers of the section loop (soft_append_bcthw, crop_or_pad_yield_mask,
+repeat_to_batch_size).  Shared by tests/golden/make_golden.py (which feeds them to the reference's own
+diffusers_helper/utils.py and stores the outputs in tests/golden/utils.npz) and tests/test_sections_cpu.py."""
+import torch
+
+
+def _randn(seed, shape, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g).to(dtype)
+
+
+def soft_append_cases():
+    """name -> (history, current, overlap); pixel clips [B, C, T, H, W] as the worker appends them (worker.py:713)."""
+    return {
+        "no_overlap": (_randn(1, (1, 3, 5, 4, 6)), _randn(2, (1, 3, 4, 4, 6)), 0),
+        "negative_overlap": (_randn(3, (1, 3, 2, 4, 6)), _randn(4, (1, 3, 3, 4, 6)), -2),
+        "overlap_3": (_randn(5, (1, 3, 9, 4, 6)), _randn(6, (1, 3, 7, 4, 6)), 3),
+        "overlap_1": (_randn(7, (2, 3, 4, 2, 2)), _randn(8, (2, 3, 4, 2, 2)), 1),
+        "overlap_all_of_history": (_randn(9, (1, 3, 5, 4, 6)), _randn(10, (1, 3, 8, 4, 6)), 5),
+        "overlap_all_of_current": (_randn(11, (1, 3, 8, 4, 6)), _randn(12, (1, 3, 5, 4, 6)), 5),
+        # the product's own sizes in miniature: window 9 -> 33 new frames, overlap 4*9-3 = 33
+        "section_overlap_33": (_randn(13, (1, 3, 36, 2, 2)), _randn(14, (1, 3, 69, 2, 2)), 33),
+        "fp16": (_randn(15, (1, 3, 6, 4, 6), torch.float16), _randn(16, (1, 3, 6, 4, 6), torch.float16), 4),
+        "bf16_history_fp32_current": (_randn(17, (1, 3, 6, 2, 2), torch.bfloat16), _randn(18, (1, 3, 6, 2, 2)), 2),
+    }
+
+
+def crop_or_pad_cases():
+    """name -> (x [B, F, C], length)."""
+    return {
+        "pad": (_randn(21, (1, 37, 16)), 64),
+        "pad_batch_fp16": (_randn(22, (2, 5, 8), torch.float16), 12),
+        "equal": (_randn(23, (1, 64, 16)), 64),
+        "crop": (_randn(24, (1, 90, 16)), 64),
+        "empty": (_randn(25, (1, 0, 16)), 8),
+    }
+
+
+def repeat_cases():
+    """name -> (tensor, batch_size)."""
+    return {
+        "same": (_randn(31, (2, 3, 4)), 2),
+        "times_3": (_randn(32, (1, 3, 4)), 3),
+        "times_2_of_2": (_randn(33, (2, 5)), 4),
+        "uneven": (_randn(34, (2, 5)), 3),
+    }
