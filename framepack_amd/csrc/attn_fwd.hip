@@ -43,7 +43,9 @@ __device__ __forceinline__ unsigned v_lds_off(int key, int chunk) {
 __device__ __forceinline__ float other_half(float x) {
     const unsigned u = __float_as_uint(x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+    unsigned t = threadIdx.x;                    // opaque: the half bit is derived where it is used, not carried as a
+    asm volatile("" : "+v"(t));                  // register (or a 64-bit mask) through the tile loops
+    return __uint_as_float((t & 32) ? r[0] : r[1]);
 }
 
 // ======================================================================================================
@@ -78,6 +80,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ __forceinline__ void dma16(const void* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+}
+// the same with the instruction's immediate offset, which the hardware adds to BOTH addresses
+template <int OFF> __device__ __forceinline__ void dma16_at(const void* src, unsigned char* dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, OFF, 0);
 }
 // a[IDX:IDX+15] += A . B after at most LGKM LDS reads are left in flight (the V^T fragments are read by inline asm -
 // see rd_v - so the compiler does not count them)
@@ -615,22 +621,57 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     const unsigned k_step = (unsigned)(KVBLK * k_rs * 2), v_step = (unsigned)(KVBLK * v_rs * 2);
     const unsigned k_rowmax = (unsigned)((seg_hi - 1) * k_rs * 2), v_rowmax = (unsigned)((seg_hi - 1) * v_rs * 2);
     const unsigned k_i = (unsigned)(4 * k_rs * 2), v_i = (unsigned)(16 * v_rs * 2);
-    unsigned k_row0 = (unsigned)((wave * 16 + (lane >> 4)) * k_rs * 2);          // lane term of the K row
-    unsigned v_row0 = (unsigned)((lane >> 2) * v_rs * 2);                        // lane term of the V row
+    const unsigned k_row0 = (unsigned)((wave * 16 + (lane >> 4)) * k_rs * 2);    // lane term of the K row
+    const unsigned v_row0 = (unsigned)((lane >> 2) * v_rs * 2);                  // lane term of the V row
     unsigned k_tile = (unsigned)((seg_lo + t0 * KVBLK) * k_rs * 2);              // next K tile to load (scalar)
     unsigned v_tile = (unsigned)((seg_lo + t0 * KVBLK) * v_rs * 2);              // next V tile to load (scalar)
     const unsigned v_col = (unsigned)((head * HD + wave * 32 + (lane & 3) * 8) * 2);
     // K column of piece i: the chunk that belongs at this lane's LDS position under the image's XOR,
     // ((lane & 15) ^ ((4 i + (lane >> 4)) & 15)) * 16 B = k_col0 ^ (i << 6)
-    unsigned k_col0 = (unsigned)(head * HD * 2) + (((lane & 15) ^ (lane >> 4)) << 4);
-    auto issue_k = [&](int i, int slot) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(k_row0), "+v"(k_col0));
-        const unsigned off = min(k_row0 + (k_tile + i * k_i), k_rowmax) + (k_col0 ^ (unsigned)(i << 6));
+    const unsigned k_col0 = (unsigned)(head * HD * 2) + (((lane & 15) ^ (lane >> 4)) << 4);
+    // INNER = the tile lies wholly inside the segment (every step of the main loop but the last few): no row needs the
+    // clamp, and the lane term (row + XORed column) of a piece is one loop-invariant register: one add per piece in place
+    // of add / min / xor-add (a single wave pays ~4 issue cycles for every instruction it sends, scalar ones included)
+    // The four pieces of a tile go out on ONE m0 value (the slot's base): piece i reaches its LDS rows through the
+    // instruction's immediate offset (i KiB), which the hardware adds to the global address as well - taken off the
+    // lane term again.  (With the tile term in a scalar base address instead of the per-piece add, the compiler widens
+    // the lane terms into 64-bit register pairs: sixteen registers this kernel does not have.)
+    unsigned k_lane[4], v_lanes[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        k_lane[i] = k_row0 + (k_col0 ^ (unsigned)(i << 6)) + i * k_i - i * 1024;     // k_i, v_i >= 1 KiB: no wrap
+        v_lanes[i] = v_row0 + v_col + i * v_i - i * 1024;
+    }
+    auto issue_k_inner = [&](auto I, int slot, unsigned tile) __attribute__((always_inline)) {
+        const unsigned off = k_lane[I] + tile;
+        dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(K) + off, smem + slot * KBUF + wave * 16 * 256);
+    };
+    auto issue_v_inner = [&](auto I, int slot, unsigned tile) __attribute__((always_inline)) {
+        const unsigned off = v_lanes[I] + tile;
+        dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(V) + off,
+                                             smem + VRING + slot * KBUF + wave * (KVBLK * 64));
+    };
+    auto issue_k = [&](int i, int slot, auto INNER, unsigned tile) __attribute__((always_inline)) {
+        unsigned off;
+        {
+            // (row and column terms derived again from the lane number, behind an opaque copy: kept in registers across
+            //  the main loop they are three values too many and the compiler parks them in accumulator registers)
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned row = (unsigned)((wave * 16 + (ln >> 4)) * k_rs * 2);
+            const unsigned colx = (unsigned)(head * HD * 2) + ((((ln & 15) ^ (ln >> 4)) << 4) ^ (unsigned)(i << 6));
+            off = min(row + (tile + i * k_i), k_rowmax) + colx;
+        }
         dma16(reinterpret_cast<const unsigned char*>(K) + off, smem + slot * KBUF + (wave * 16 + i * 4) * 256);
     };
-    auto issue_v = [&](int i, int slot) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(v_row0));
-        const unsigned off = min(v_row0 + (v_tile + i * v_i), v_rowmax) + v_col;
+    auto issue_v = [&](int i, int slot, auto INNER, unsigned tile) __attribute__((always_inline)) {
+        unsigned off;
+        {
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));
+            const unsigned row = (unsigned)((ln >> 2) * v_rs * 2);
+            off = min(row + (tile + i * v_i), v_rowmax) + (unsigned)((head * HD + wave * 32 + (ln & 3) * 8) * 2);
+        }
         dma16(reinterpret_cast<const unsigned char*>(V) + off, smem + VRING + slot * KBUF + wave * (KVBLK * 64) + i * 1024);
     };
 
@@ -660,10 +701,14 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
 
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
     // all fragment reads are asm: invisible to the compiler's lgkmcnt bookkeeping, their consumers wait explicitly
+    // (the two key blocks of a k-step are read one after the other, kb = 0 first, and share the address register)
+    unsigned k_addr = 0;
     auto rd_k = [&](bf16x8& f, unsigned& kbase, auto KB, auto KS_) __attribute__((always_inline)) {
-        asm volatile("" : "+v"(kbase));          // opaque: else the eight XORed addresses are kept in registers
-        const unsigned a = kbase ^ (unsigned)(KS_ << 5);
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a), "n"(KB * 8192));
+        if constexpr (KB == 0) {
+            asm volatile("" : "+v"(kbase));      // opaque: else the eight XORed addresses are kept in registers
+            k_addr = kbase ^ (unsigned)(KS_ << 5);
+        }
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(k_addr), "n"(KB * 8192));
     };
     auto rd_v = [&](bf16x8& f, unsigned vbase, auto D, auto S4) __attribute__((always_inline)) {
         union {
@@ -677,19 +722,19 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
 
     // ---- prologue: K(0), K(1), V(0), K(2), V(1).  Tile j of K lives in ring slot j % 3, of V in j % 4.
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_k(i, 0);
+    for (int i = 0; i < 4; ++i) issue_k(i, 0, ic<0>{}, k_tile);
     k_tile += k_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_k(i, 1);
+    for (int i = 0; i < 4; ++i) issue_k(i, 1, ic<0>{}, k_tile);
     k_tile += k_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_v(i, 0);
+    for (int i = 0; i < 4; ++i) issue_v(i, 0, ic<0>{}, v_tile);
     v_tile += v_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_k(i, 2);
+    for (int i = 0; i < 4; ++i) issue_k(i, 2, ic<0>{}, k_tile);
     k_tile += k_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_v(i, 1);
+    for (int i = 0; i < 4; ++i) issue_v(i, 1, ic<0>{}, v_tile);
     v_tile += v_step;
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // K(0), K(1), V(0) landed
     __builtin_amdgcn_s_barrier();
@@ -714,7 +759,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     int kslot_rd = 1, kslot_wr = 0;              // K(t+1) is read, K(t+3) written: for t = 0
     int vslot_rd = 0, vslot_nx = 0, vslot_wr = 2;   // V(t-1) (V(0) for t = 0) is read, V(t) prefetched, V(t+2) written
     // One tile step.  PAR = t & 1: S(t) sits in S[PAR], S(t+1) is accumulated into S[1 - PAR].
-    auto step = [&](int t, auto PAR) __attribute__((always_inline)) {
+    auto step = [&](int t, auto PAR, auto INNER) __attribute__((always_inline)) {
         constexpr int CUR = PAR, NXT = 1 - PAR;
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // all but this wave's last 8 pieces: K(t+1), V(t) are in
         if constexpr (!(FP_V3_SKIP & 8)) __builtin_amdgcn_s_barrier();
@@ -722,6 +767,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         unsigned kbase = (unsigned)(kslot_rd * KBUF) + k_lane_base;
         const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
         const bool first = t == 0;
+        // the tile terms of this step's DMA sources, opaque: else loop strength reduction turns the eight pieces of both
+        // step parities into sixteen per-lane induction registers
+        unsigned kt = k_tile, vt = v_tile;
+        asm volatile("" : "+s"(kt), "+s"(vt));
         float ev[4], rs[2] = {0.f, 0.f};     // exp ring: at most four values wait for their add / pack
         // row-sum add of exp h and, with the second value of a pair, the pack into its P^T dword
         auto finish_exp = [&](auto H_) __attribute__((always_inline)) {
@@ -740,10 +789,12 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
                 pf[rb][s4] = pk.v;
             }
         };
-        if ((t0 + t == nt_all - 1) && (nkv & (KVBLK - 1))) {          // ragged last tile: keys past the end score -inf
+        if (!INNER && (t0 + t == nt_all - 1) && (nkv & (KVBLK - 1))) {          // ragged last tile: keys past the end score -inf
             // the lane's first invalid key offset, opaque and defined in here: hoisted out of the loop, the 32 compare
             // masks would sit in 64 SGPRs for the whole sweep
-            int lim = nkv - (t0 + t) * KVBLK - 4 * hh;
+            unsigned ln = (unsigned)lane;
+            asm volatile("" : "+v"(ln));
+            int lim = nkv - (t0 + t) * KVBLK - 4 * (int)(ln >> 5);
             asm volatile("s_nop 15\ns_nop 7" : "+v"(lim)::"memory");  // (and the last MFMAs of S(t) have retired)
 #pragma unroll
             for (int rb2 = 0; rb2 < 2; ++rb2)
@@ -783,8 +834,13 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             // ---------------- LDS-DMA: K(t+3) and V(t+2)
             if constexpr (v3_dma_of_slot(m) >= 0 && !(FP_V3_SKIP & 4)) {
                 constexpr int i = v3_dma_of_slot(m);
-                if constexpr (i < 4) issue_k(i, kslot_wr);
-                else issue_v(i - 4, vslot_wr);
+                if constexpr (INNER) {
+                    if constexpr (i < 4) issue_k_inner(ic<i>{}, kslot_wr, kt);
+                    else issue_v_inner(ic<i - 4>{}, vslot_wr, vt);
+                } else {
+                    if constexpr (i < 4) issue_k(i, kslot_wr, INNER, kt);
+                    else issue_v(i - 4, vslot_wr, INNER, vt);
+                }
             }
             // ---------------- P(t) = exp2(S(t)): exp h of the tile (two values per P^T dword, in the order the k-steps use
             // them) is issued in gap 8 + 7h/8; its row-sum add and the pack of its pair follow one gap LATER, so that no
@@ -804,7 +860,8 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         if constexpr (!(FP_V3_SKIP & 1)) finish_exp(ic<63>{});
         // ---------------- did a row's max grow by more than THR?  Then some P = exp2(s - m) of that row exceeds 2^THR and
         // so does the tile's row sum (an overflow to inf or a NaN fails the test too): redo the tile on the slow path
-        bool slow = first || !__all(rs[0] <= rs_limit && rs[1] <= rs_limit);
+        // (one max, one compare, one branch on vcc; a NaN sum needs no redo - the row is NaN either way)
+        bool slow = first || __builtin_amdgcn_ballot_w64(!(fmaxf(rs[0], rs[1]) <= rs_limit)) != 0;
         if constexpr (FP_V3_SKIP & 128) slow = first;
         if (slow) {
             asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory"); // every MFMA of this iteration has retired
@@ -884,12 +941,19 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     }
 #endif
     {
+        // step t loads K(t+3) and V(t+2) (tiles counted from t0): all of their rows are the segment's own while
+        // t0 + t + 3 < nkv / 64.  Those steps run without the per-row clamp; the last few (and a short segment) with it.
+        const int n_inner = max(min(nt, nkv / KVBLK - t0 - 3), 0) & ~1;
         int t = 0;
-        for (; t + 1 < nt; t += 2) {
-            step(t, ic<0>{});
-            step(t + 1, ic<1>{});
+        for (; t < n_inner; t += 2) {
+            step(t, ic<0>{}, ic<1>{});
+            step(t + 1, ic<1>{}, ic<1>{});
         }
-        if (t < nt) step(t, ic<0>{});
+        for (; t + 1 < nt; t += 2) {
+            step(t, ic<0>{}, ic<0>{});
+            step(t + 1, ic<1>{}, ic<0>{});
+        }
+        if (t < nt) step(t, ic<0>{}, ic<0>{});
     }
 #ifdef FP_V3_DIAG
     if (blockIdx.x == 8 && tid == 0) {
@@ -916,10 +980,17 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     float l_tot[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) l_tot[rb] = l_run[rb] + other_half(l_run[rb]);
+    // lane terms of the output rows, derived again behind an opaque copy: shared with the prologue's they would be carried
+    // through the tile loops, which have no register to spare
+    unsigned ln_e = (unsigned)lane;
+    asm volatile("" : "+v"(ln_e));
+    const int r_e = (int)(ln_e & 31), hh_e = (int)(ln_e >> 5);
+    // (uniform; through a lane read so that it is not shared with the prologue's per-lane row, which would stay live)
+    const int qbase_e = __builtin_amdgcn_readfirstlane(q0 + wave * 64);
     if (nparts > 1) {                           // partial sweep: unnormalised O (fp32), running max and sum
         static_for<2>([&](auto rb) __attribute__((always_inline)) {
-            const int row = wave * 64 + rb * 32 + r;
-            float* op = wsp + row * HD + 4 * hh;
+            const int row = wave * 64 + rb * 32 + r_e;
+            float* op = wsp + row * HD + 4 * hh_e;
             static_for<4>([&](auto d) __attribute__((always_inline)) {
                 static_for<4>([&](auto g) __attribute__((always_inline)) {
                     f32x4 v;
@@ -927,7 +998,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
                     *reinterpret_cast<f32x4*>(op + d * 32 + g * 8) = v;
                 });
             });
-            if (hh == 0) {
+            if (hh_e == 0) {
                 wsp[256 * HD + row] = -negm[rb][0];
                 wsp[256 * HD + 256 + row] = l_tot[rb];
             }
@@ -936,9 +1007,9 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     }
     static_for<2>([&](auto rb) __attribute__((always_inline)) {
         const float inv = 1.f / l_tot[rb];
-        const int qrow_real = q0 + wave * 64 + rb * 32 + r;
+        const int qrow_real = qbase_e + rb * 32 + r_e;
         if (qrow_real < seg_hi) {
-            bf16* op = O + (int64_t)qrow_real * o_rs + head * HD + 4 * hh;
+            bf16* op = O + (int64_t)qrow_real * o_rs + head * HD + 4 * hh_e;
             static_for<4>([&](auto d) __attribute__((always_inline)) {
                 static_for<4>([&](auto g) __attribute__((always_inline)) {
                     bf16x4 v;
