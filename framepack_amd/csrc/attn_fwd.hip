@@ -644,12 +644,12 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     }
     auto issue_k_inner = [&](auto I, int slot, unsigned tile) __attribute__((always_inline)) {
         const unsigned off = k_lane[I] + tile;
-        dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(K) + off, smem + slot * KBUF + wave * 16 * 256);
+        dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(K) + off, smem + slot + wave * 16 * 256);
     };
     auto issue_v_inner = [&](auto I, int slot, unsigned tile) __attribute__((always_inline)) {
         const unsigned off = v_lanes[I] + tile;
         dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(V) + off,
-                                             smem + VRING + slot * KBUF + wave * (KVBLK * 64));
+                                             smem + VRING + slot + wave * (KVBLK * 64));
     };
     auto issue_k = [&](int i, int slot, auto INNER, unsigned tile) __attribute__((always_inline)) {
         unsigned off;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             const unsigned colx = (unsigned)(head * HD * 2) + ((((ln & 15) ^ (ln >> 4)) << 4) ^ (unsigned)(i << 6));
             off = min(row + (tile + i * k_i), k_rowmax) + colx;
         }
-        dma16(reinterpret_cast<const unsigned char*>(K) + off, smem + slot * KBUF + (wave * 16 + i * 4) * 256);
+        dma16(reinterpret_cast<const unsigned char*>(K) + off, smem + slot + (wave * 16 + i * 4) * 256);
     };
     auto issue_v = [&](int i, int slot, auto INNER, unsigned tile) __attribute__((always_inline)) {
         unsigned off;
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             const unsigned row = (unsigned)((ln >> 2) * v_rs * 2);
             off = min(row + (tile + i * v_i), v_rowmax) + (unsigned)((head * HD + wave * 32 + (ln & 3) * 8) * 2);
         }
-        dma16(reinterpret_cast<const unsigned char*>(V) + off, smem + VRING + slot * KBUF + wave * (KVBLK * 64) + i * 1024);
+        dma16(reinterpret_cast<const unsigned char*>(V) + off, smem + VRING + slot + wave * (KVBLK * 64) + i * 1024);
     };
 
     // ---- fragment read addresses
@@ -687,6 +687,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     f32x16 negm[2];                              // -m_run[rb] in all 16 registers: the C operand of a chain's first MFMA
     bf16x8 pf[2][4];                             // P(t-1)/P(t): [rb][k-step]
     bf16x8 fr[4];                                // fragment ring (three fragments = 6 MFMAs ahead), carried across tiles
+    float lim_cur = -1.f;                        // the growth test's limit (scalar)
     float l_run[2] = {0.f, 0.f};                 // the running max of a row block is -negm[rb][0]
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -725,16 +726,16 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     for (int i = 0; i < 4; ++i) issue_k(i, 0, ic<0>{}, k_tile);
     k_tile += k_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_k(i, 1, ic<0>{}, k_tile);
+    for (int i = 0; i < 4; ++i) issue_k(i, KBUF, ic<0>{}, k_tile);
     k_tile += k_step;
 #pragma unroll
     for (int i = 0; i < 4; ++i) issue_v(i, 0, ic<0>{}, v_tile);
     v_tile += v_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_k(i, 2, ic<0>{}, k_tile);
+    for (int i = 0; i < 4; ++i) issue_k(i, 2 * KBUF, ic<0>{}, k_tile);
     k_tile += k_step;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) issue_v(i, 1, ic<0>{}, v_tile);
+    for (int i = 0; i < 4; ++i) issue_v(i, KBUF, ic<0>{}, v_tile);
     v_tile += v_step;
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // K(0), K(1), V(0) landed
     __builtin_amdgcn_s_barrier();
@@ -756,17 +757,17 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     rd_v(fr[1], v_lane_off, ic<1>{}, ic<0>{});
     rd_v(fr[2], v_lane_off, ic<2>{}, ic<0>{});
 
-    int kslot_rd = 1, kslot_wr = 0;              // K(t+1) is read, K(t+3) written: for t = 0
-    int vslot_rd = 0, vslot_nx = 0, vslot_wr = 2;   // V(t-1) (V(0) for t = 0) is read, V(t) prefetched, V(t+2) written
+    // ring positions as BYTE offsets (no shift per use)
+    int kslot_rd = KBUF, kslot_wr = 0;           // K(t+1) is read, K(t+3) written: for t = 0
+    int vslot_rd = 0, vslot_nx = 0, vslot_wr = 2 * KBUF;   // V(t-1) (V(0) for t = 0) is read, V(t) prefetched, V(t+2) written
     // One tile step.  PAR = t & 1: S(t) sits in S[PAR], S(t+1) is accumulated into S[1 - PAR].
     auto step = [&](int t, auto PAR, auto INNER) __attribute__((always_inline)) {
         constexpr int CUR = PAR, NXT = 1 - PAR;
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // all but this wave's last 8 pieces: K(t+1), V(t) are in
         if constexpr (!(FP_V3_SKIP & 8)) __builtin_amdgcn_s_barrier();
         fence();
-        unsigned kbase = (unsigned)(kslot_rd * KBUF) + k_lane_base;
-        const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
-        const bool first = t == 0;
+        unsigned kbase = (unsigned)kslot_rd + k_lane_base;
+        const unsigned vbase = (unsigned)vslot_rd + v_lane_off;
         // the tile terms of this step's DMA sources, opaque: else loop strength reduction turns the eight pieces of both
         // step parities into sixteen per-lane induction registers
         unsigned kt = k_tile, vt = v_tile;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
                 constexpr int f2 = f + 3;
                 if constexpr (f2 < 16) rd_v(fr[f2 & 3], vbase, ic<f2 & 3>{}, ic<(f2 >> 2)>{});
                 else if constexpr (f2 < 32) rd_k(fr[f2 & 3], kbase, ic<(f2 - 16) & 1>{}, ic<((f2 - 16) >> 1)>{});
-                else rd_v(fr[f2 & 3], (unsigned)(vslot_nx * KBUF) + v_lane_off, ic<(f2 - 32) & 3>{}, ic<0>{});
+                else rd_v(fr[f2 & 3], (unsigned)vslot_nx + v_lane_off, ic<(f2 - 32) & 3>{}, ic<0>{});
             }
             // ---------------- LDS-DMA: K(t+3) and V(t+2)
             if constexpr (v3_dma_of_slot(m) >= 0 && !(FP_V3_SKIP & 4)) {
@@ -861,9 +862,12 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         // ---------------- did a row's max grow by more than THR?  Then some P = exp2(s - m) of that row exceeds 2^THR and
         // so does the tile's row sum (an overflow to inf or a NaN fails the test too): redo the tile on the slow path
         // (one max, one compare, one branch on vcc; a NaN sum needs no redo - the row is NaN either way)
-        bool slow = first || __builtin_amdgcn_ballot_w64(!(fmaxf(rs[0], rs[1]) <= rs_limit)) != 0;
-        if constexpr (FP_V3_SKIP & 128) slow = first;
+        // The first tile always goes this way: its limit is -1 (row sums are >= 0), set to 2^THR in there.
+        bool slow = __builtin_amdgcn_ballot_w64(!(fmaxf(rs[0], rs[1]) <= lim_cur)) != 0;
+        if constexpr (FP_V3_SKIP & 128) slow = t == 0;
         if (slow) {
+            const bool first = t == 0;
+            lim_cur = rs_limit;
             asm volatile("s_nop 15\ns_nop 15\ns_nop 7" ::: "memory"); // every MFMA of this iteration has retired
             float alpha[2];
 #pragma unroll
@@ -920,10 +924,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         k_tile += k_step;
         v_tile += v_step;
         kslot_wr = kslot_rd;                                          // K(t+4) goes where K(t+1) was
-        kslot_rd = kslot_rd == 2 ? 0 : kslot_rd + 1;
+        kslot_rd = kslot_rd == 2 * KBUF ? 0 : kslot_rd + KBUF;
         vslot_rd = vslot_nx;                                          // next: P.V reads V(t), prefetches V(t+1), loads V(t+3)
-        vslot_nx = (vslot_nx + 1) & 3;
-        vslot_wr = (vslot_wr + 1) & 3;
+        vslot_nx = (vslot_nx + KBUF) & (4 * KBUF - 1);
+        vslot_wr = (vslot_wr + KBUF) & (4 * KBUF - 1);
         // The compiler does not know that the asm above writes S(t+1) with a 16-pass MFMA: a register copy it places
         // behind this step (it does, on the way from the loop to the odd last step) must not come within 18 wait
         // states of the last MFMA.  The end-of-tile check above covers about half of them.
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("" ::"v"(fr[0]), "v"(fr[1]), "v"(fr[2]));    // registers of the in-flight prefetch stay allocated until here
     {
-        const unsigned vbase = (unsigned)(vslot_rd * KBUF) + v_lane_off;
+        const unsigned vbase = (unsigned)vslot_rd + v_lane_off;
         static_for<4>([&](auto s4) __attribute__((always_inline)) {
             static_for<4>([&](auto d) __attribute__((always_inline)) {
                 bf16x8 f;
