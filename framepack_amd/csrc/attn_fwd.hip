@@ -85,6 +85,10 @@ __device__ __forceinline__ void dma16(const void* src, unsigned char* dst) {
 template <int OFF> __device__ __forceinline__ void dma16_at(const void* src, unsigned char* dst) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, OFF, 0);
 }
+template <int OFF> __device__ __forceinline__ void dma16_buf(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff,
+                                                            unsigned char* dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)dst, 16, voff, soff, OFF, 0);
+}
 // a[IDX:IDX+15] += A . B after at most LGKM LDS reads are left in flight (the V^T fragments are read by inline asm -
 // see rd_v - so the compiler does not count them)
 template <int IDX, int LGKM> __device__ __forceinline__ void mfma32_after(const bf16x8& a, const bf16x8& b) {
@@ -642,14 +646,15 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         k_lane[i] = k_row0 + (k_col0 ^ (unsigned)(i << 6)) + i * k_i - i * 1024;     // k_i, v_i >= 1 KiB: no wrap
         v_lanes[i] = v_row0 + v_col + i * v_i - i * 1024;
     }
+    // Buffer form of the LDS-DMA: address = descriptor base + lane term (register, loop-invariant) + tile term (SCALAR
+    // offset operand) + immediate - no vector instruction per piece at all.
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, -1, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, -1, 0x00020000);
     auto issue_k_inner = [&](auto I, int slot, unsigned tile) __attribute__((always_inline)) {
-        const unsigned off = k_lane[I] + tile;
-        dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(K) + off, smem + slot + wave * 16 * 256);
+        dma16_buf<decltype(I)::value * 1024>(k_rsrc, k_lane[I], tile, smem + slot + wave * 16 * 256);
     };
     auto issue_v_inner = [&](auto I, int slot, unsigned tile) __attribute__((always_inline)) {
-        const unsigned off = v_lanes[I] + tile;
-        dma16_at<decltype(I)::value * 1024>(reinterpret_cast<const unsigned char*>(V) + off,
-                                             smem + VRING + slot + wave * (KVBLK * 64));
+        dma16_buf<decltype(I)::value * 1024>(v_rsrc, v_lanes[I], tile, smem + VRING + slot + wave * (KVBLK * 64));
     };
     auto issue_k = [&](int i, int slot, auto INNER, unsigned tile) __attribute__((always_inline)) {
         unsigned off;
