@@ -339,6 +339,9 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.sp_chunks = None          # head chunks per exchange (None: ulysses.pick_chunks decides)
         self._sp_total = 0
         self.fp8_compute = False       # block linears on the fp8 MFMA (enable_fp8_compute)
+        # text stream of the double blocks on a low-priority side stream (_double_block); FRAMEPACK_TEXT_OVERLAP=0: off
+        self.text_stream_overlap = os.environ.get("FRAMEPACK_TEXT_OVERLAP", "1") != "0"
+        self._side_streams = {}
         self.fp8_attention = False     # joint attention with e4m3 Q, K, P, V (enable_fp8_attention)
 
     # ---- reference API ---------------------------------------------------------------------
@@ -670,23 +673,55 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         aq, asc = ops.layernorm_modulate_fp8(x, sc, sh, out=ws.Q[:M * K].view(M, K), out_scale=ws.QS[:M])
         return ops.gemm_fp8(aq, asc, w[0], w[1], b, **kw)
 
-    def _double_block(self, e, mod_i, mod_c, ws, Si, S, rope):
+    def _double_block(self, e, mod_i, mod_c, ws, Si, S, rope, side=None):
+        """One double-stream block (ref :537-604).  The two streams meet only in the joint attention: everything else of
+        the text stream (its rows of X, N, Y; its own weights) is independent of the image stream's.  With `side`
+        (= (stream, event after the text stream's last kernel so far); `_run_blocks`) the text stream's kernels go to
+        that low-priority HIP stream: its GEMMs have 48 - 192 tiles for 256 CUs and run in the CUs that the image
+        stream's GEMMs leave idle in their last, partly filled round instead of in launches of their own.  Two joins per
+        block: the attention waits for the text q | k | v, the text out-projection for the attention."""
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         sh_a, sc_a, g_a, sh_m, sc_m, g_m = mod_i.chunk(6)
         csh_a, csc_a, cg_a, csh_m, csc_m, cg_m = mod_c.chunk(6)
         qkv = Y[:, :3 * d]
-        self._ln_lin(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
-        self._ln_lin(ws, X[Si:], csc_a, csh_a, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
         q, k, v = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
-        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, wq_txt=e.nq_c, wk_txt=e.nk_c)
-        self._lin(ws, q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_a)
-        self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_a)
         Fh = Y[:, 3 * d:]
+        GR = ops.EPI_GATE_RESIDUAL
+
+        def text_pre():
+            self._ln_lin(ws, X[Si:], csc_a, csh_a, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
+
+        def text_post():
+            self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_a)
+            self._ln_lin(ws, X[Si:], csc_m, csh_m, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
+            self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_m)
+
+        main = torch.cuda.current_stream(X.device) if side is not None else None
+        self._ln_lin(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
+        if side is None:
+            text_pre()
+        else:
+            with torch.cuda.stream(side[0]):
+                text_pre()
+                side[1].record(side[0])
+            main.wait_event(side[1])
+        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, wq_txt=e.nq_c, wk_txt=e.nk_c)
+        if side is not None:
+            side[2].record(main)
+            side[0].wait_event(side[2])
+            with torch.cuda.stream(side[0]):
+                text_post()
+                side[1].record(side[0])
+        self._lin(ws, q[:Si], e.w_out, e.b_out, out=X[:Si], epilogue=GR, resid=X[:Si], gate=g_a)
+        if side is None:
+            self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_a)
         self._ln_lin(ws, X[:Si], sc_m, sh_m, N[:Si], e.w_ff1, e.b_ff1, out=Fh[:Si], epilogue=ops.EPI_GELU)
-        self._ln_lin(ws, X[Si:], csc_m, csh_m, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
-        self._lin(ws, Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[:Si], gate=g_m)
-        self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=ops.EPI_GATE_RESIDUAL, resid=X[Si:], gate=cg_m)
+        if side is None:
+            self._ln_lin(ws, X[Si:], csc_m, csh_m, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
+        self._lin(ws, Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=GR, resid=X[:Si], gate=g_m)
+        if side is None:
+            self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_m)
 
     def _single_block(self, e, mod, ws, Si, S, rope):
         d, H = self.inner_dim, self.heads
@@ -698,14 +733,34 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._qk_attend(q, k, v, e.nq, e.nk, rope, Si)
         self._lin(ws, Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
 
+    def _text_side_stream(self, device):
+        """(low-priority stream, two events) for the text stream of the double blocks, per device; None where the
+        overlap is off: fp8 compute (one shared quantiser scratch), sequence parallelism (rows are not split by stream
+        there), block taps (they read X between blocks), `text_stream_overlap = False`."""
+        if not self.text_stream_overlap or self.sp_world != 1 or self.taps is not None or self.fp8_compute:
+            return None
+        key = device.index
+        if key not in self._side_streams:
+            least = torch.cuda.Stream.priority_range()[0] if hasattr(torch.cuda.Stream, "priority_range") else 0
+            self._side_streams[key] = (torch.cuda.Stream(device=device, priority=least), torch.cuda.Event(),
+                                       torch.cuda.Event())
+        return self._side_streams[key]
+
     def _run_blocks(self, P, mods, ws, Si, S, rope):
         d = self.inner_dim
         o = 0
+        side = self._text_side_stream(ws.X.device) if len(P.double) and S > Si else None
+        if side is not None:                        # the side stream starts behind everything queued so far
+            main = torch.cuda.current_stream(ws.X.device)
+            side[2].record(main)
+            side[0].wait_event(side[2])
         for i, e in enumerate(P.double):
-            self._double_block(e, mods[o:o + 6 * d], mods[o + 6 * d:o + 12 * d], ws, Si, S, rope)
+            self._double_block(e, mods[o:o + 6 * d], mods[o + 6 * d:o + 12 * d], ws, Si, S, rope, side)
             o += 12 * d
             if self.taps is not None:
                 self.taps[f"double.{i}"] = (ws.X[:Si].clone(), ws.X[Si:].clone())
+        if side is not None:                        # the single blocks read all rows
+            main.wait_event(side[1])
         for i, e in enumerate(P.single):
             self._single_block(e, mods[o:o + 3 * d], ws, Si, S, rope)
             o += 3 * d

@@ -374,3 +374,35 @@ def test_full_width_blocks_match_oracle():
     assert rel_l2(got, ref) < TOL
     del m
     torch.cuda.empty_cache()
+
+
+def test_text_stream_on_the_side_stream_changes_nothing(tiny):
+    """The double blocks run the text stream's kernels on a low-priority side stream (model._double_block) with two
+    joins per block.  The kernels are deterministic, so the output must be BIT-identical to the single-stream order -
+    for the tiny model over several cases and repeats, and at 13B width with three double blocks, where the image
+    GEMMs run for multiple rounds while the text ones queue beside them (a missing join shows up here)."""
+    m, _ = tiny
+    assert m.text_stream_overlap and m._text_side_stream(torch.device(DEV)) is not None
+    for case in ("config1", "odd_bucket_pad", "max_text_tail"):
+        kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES[case]))
+        m.text_stream_overlap = False
+        want = m(return_dict=False, **kw)[0].clone()
+        m.text_stream_overlap = True
+        for _ in range(3):
+            assert torch.equal(m(return_dict=False, **kw)[0], want), case
+    # taps, fp8 compute and sequence parallelism switch the side stream off
+    m.taps = {}
+    assert m._text_side_stream(torch.device(DEV)) is None
+    m.taps = None
+
+    cfg_kw = dict(synthetic.CONFIG_13B, num_layers=3, num_single_layers=1)
+    big, _ = build(cfg_kw, seed=2)
+    kw = to_dev(synthetic.make_inputs(dtype=BF, seed=11, frames_latent=9, height=320, width=320, n_text=256, sigma=0.6))
+    big.text_stream_overlap = False
+    want = big(return_dict=False, **kw)[0].clone()
+    big.text_stream_overlap = True
+    for _ in range(3):
+        got = big(return_dict=False, **kw)[0]
+        assert torch.isfinite(got.float()).all() and torch.equal(got, want)
+    del big
+    torch.cuda.empty_cache()
