@@ -226,31 +226,41 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
 
     };
     const int nk = K / BKE;
-    auto src_a = [&](int h, int j, int t) __attribute__((always_inline)) -> const T* {
+    // AMODE 1: a K tile is one tap x 64 or 128 channels, and with Cin >= 2 K tiles per tap (the launcher sends narrower
+    // inputs to the 8-wave kernel) the tiles 2 i and 2 i + 1 share their tap: the piece's source offset is worked out
+    // at the EVEN tile and kept for the odd one (poff), which halves the gather's vector instructions - a lone wave per
+    // SIMD pays an issue slot for every one of them.  Which call is which is known at compile time (below).
+    unsigned poff[2][4];
+    auto tap_off = [&](int h, int j, int t) __attribute__((always_inline)) -> unsigned {
+        const unsigned k0 = (unsigned)t * BKE;
+        const unsigned tap = k0 >> cg.lcin;                                      // (uniform; tap < 27)
+        const unsigned t3 = (tap * 11u) >> 5, it = (tap * 57u) >> 9;             // tap / 3, tap / 9
+        const unsigned ih = t3 - 3u * it, iw = tap - 3u * t3;
+        const int code = (int)ccode[h][j];
+        const int dT = __builtin_amdgcn_sbfe(code, 2 * it, 2), dH = __builtin_amdgcn_sbfe(code, 6 + 2 * ih, 2),
+                  dW = __builtin_amdgcn_sbfe(code, 12 + 2 * iw, 2);
+        const int dvox = __mul24(dT, cg.Hi * cg.Wi) + __mul24(dH, cg.Wi) + dW;
+        return coff[h][j] + ((unsigned)dvox << (cg.lcin - LOG2_CE));
+    };
+    auto src_a = [&](int h, int j, int t, auto EVEN) __attribute__((always_inline)) -> const T* {
         if (AMODE == 0) {
             const int64_t koff = (int64_t)t * BKE + ((t * BKE >= k1) ? a2_delta : 0);
             asm volatile("" : "+v"(pa[h][j]));      // keeps "base + lane offset" from being hoisted as a 64-bit register pair
             return reinterpret_cast<const T*>(abase + koff * (int64_t)sizeof(T) + pa[h][j]);
         } else {
-            const unsigned k0 = (unsigned)t * BKE;
-            const unsigned tap = k0 >> cg.lcin, c0 = k0 & (unsigned)(cg.Cin - 1);    // (uniform; tap < 27)
-            const unsigned t3 = (tap * 11u) >> 5, it = (tap * 57u) >> 9;             // tap / 3, tap / 9
-            const unsigned ih = t3 - 3u * it, iw = tap - 3u * t3;
-            const int code = (int)ccode[h][j];
-            const int dT = __builtin_amdgcn_sbfe(code, 2 * it, 2), dH = __builtin_amdgcn_sbfe(code, 6 + 2 * ih, 2),
-                      dW = __builtin_amdgcn_sbfe(code, 12 + 2 * iw, 2);
-            const int dvox = __mul24(dT, cg.Hi * cg.Wi) + __mul24(dH, cg.Wi) + dW;
-            const unsigned off16 = coff[h][j] + ((unsigned)dvox << (cg.lcin - LOG2_CE));
-            return reinterpret_cast<const T*>(reinterpret_cast<const char*>(A + c0) + ((uint64_t)off16 << 4));
+            const unsigned c0 = ((unsigned)t * BKE) & (unsigned)(cg.Cin - 1);        // (uniform)
+            if constexpr (EVEN) poff[h][j] = tap_off(h, j, t);
+            return reinterpret_cast<const T*>(reinterpret_cast<const char*>(A + c0) + ((uint64_t)poff[h][j] << 4));
         }
     };
     auto src_w = [&](int j, int t) __attribute__((always_inline)) -> const T* {
         asm volatile("" : "+v"(pw[j]));
         return reinterpret_cast<const T*>(wbase + (int64_t)t * (BKE * (int)sizeof(T)) + pw[j]);
     };
-    auto issue_a1 = [&](int h, int j, int t) __attribute__((always_inline)) {
+    // EVEN: t is even before the clamp (clamped, an even and the odd call behind it both name tile nk - 1)
+    auto issue_a1 = [&](int h, int j, int t, auto EVEN) __attribute__((always_inline)) {
         t = min(t, nk - 1);
-        dma16(src_a(h, j, t), smem + (t & 1) * OP_BYTES + arow0[h][j] * 128);
+        dma16(src_a(h, j, t, EVEN), smem + (t & 1) * OP_BYTES + arow0[h][j] * 128);
     };
     auto issue_w1 = [&](int j, int t) __attribute__((always_inline)) {
         t = min(t, nk - 1);
@@ -260,13 +270,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (12 + 2 NT loads per wave)
     auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_a1(0, j, 0);
+        for (int j = 0; j < 4; ++j) issue_a1(0, j, 0, ic<1>{});
 #pragma unroll
         for (int j = 0; j < NT; ++j) issue_w1(j, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_a1(1, j, 0);
+        for (int j = 0; j < 4; ++j) issue_a1(1, j, 0, ic<1>{});
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_a1(0, j, 1);
+        for (int j = 0; j < 4; ++j) issue_a1(0, j, 1, ic<0>{});
 #pragma unroll
         for (int j = 0; j < NT; ++j) issue_w1(j, 1);
     };
@@ -339,10 +349,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         if constexpr (P == 0) {
             if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * g4>{});
             if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * g4 + 1>{});
-            if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1);
+            if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1, ic<(BUF == 1)>{});      // t is odd in buffer 1
         } else {
             if constexpr (k == 2) {
-                if constexpr (g < 4) issue_a1(0, g, t + 2);
+                if constexpr (g < 4) issue_a1(0, g, t + 2, ic<(BUF == 0)>{});
                 else if constexpr (g - 4 < NT) issue_w1(g - 4, t + 2);
             }
             if constexpr (k == 5 && 2 + g < NT) issue_w1(2 + g, t + 2);
@@ -381,10 +391,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     fence();
                     if constexpr (P == 0) {
                         if constexpr (mi == 0) rd_w8(BUF, ic<n + 2>{});
-                        if constexpr (mi == 2 && n < 4) issue_a1(1, n, t + 1);
+                        if constexpr (mi == 2 && n < 4) issue_a1(1, n, t + 1, ic<(BUF == 1)>{});
                     } else {
                         if constexpr (mi == 0) {
-                            if constexpr (n < 4) issue_a1(0, n, t + 2);
+                            if constexpr (n < 4) issue_a1(0, n, t + 2, ic<(BUF == 0)>{});
                             else issue_w1(n - 4, t + 2);
                         }
                         if constexpr (mi == 2) issue_w1(2 + n, t + 2);
@@ -592,6 +602,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         // the operand pointers are recomputed rather than kept across the epilogue (32 VGPRs it needs itself)
         asm volatile("" : "+s"(vb));
         setup(vb);
+        if (AMODE == 1) {                      // (not carried across the epilogue either: phase 0 reuses tile 0's for A-h1)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) poff[1][j] = tap_off(1, j, 0);
+        }
         // a ragged tile skips stores, so the relaxed count would not cover the loads: drain instead
         if (em0 + BM > M || en0 + 2 * CW > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         relaxed = true;

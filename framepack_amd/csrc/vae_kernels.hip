@@ -65,10 +65,12 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
     FP_REQUIRE((cg.To << cg.dt) < 1024 && (cg.Ho << cg.dh) < 2048 && (cg.Wo << cg.dw) < 2048);
     const int M = (int)M64, N = Cout, K = 27 * cg.Cin;
     FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + 31) / 32) < (1ll << 31));
-    // the 4-wave kernel's gather needs Cin to be a power of two (voxel steps become shifts), 24-bit multiplies of the
-    // plane and row pitch in voxels, and sources addressable in 16-byte units from the volume's start; anything else
-    // (and outputs aligned to 8 bytes only) runs on the 8-wave kernel, which computes every source from coordinates
-    const bool pow2 = (cg.Cin & (cg.Cin - 1)) == 0 && cg.lcin == __builtin_ctz((unsigned)cg.Cin) &&
+    // the 4-wave kernel's gather needs Cin to be a power of two (voxel steps become shifts) of at least two K tiles
+    // (128 channels: K tiles 2 i and 2 i + 1 then share their tap, and the odd one reuses the even one's source offsets),
+    // 24-bit multiplies of the plane and row pitch in voxels, and sources addressable in 16-byte units from the volume's
+    // start; anything else (and outputs aligned to 8 bytes only) runs on the 8-wave kernel, which computes every source
+    // from coordinates
+    const bool pow2 = (cg.Cin & (cg.Cin - 1)) == 0 && cg.Cin >= 2 * BK && cg.lcin == __builtin_ctz((unsigned)cg.Cin) &&
                       (int64_t)cg.Hi * cg.Wi < (1 << 23) &&
                       (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin * 2 / 16 < (1ll << 32);
     const bool wide = pow2 && ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
