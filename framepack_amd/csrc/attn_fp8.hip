@@ -21,7 +21,12 @@
 //   * S^T(kb) = K8 . Q8^T: 2 MFMAs of K = 64 per 32-key block (16 in bf16), Q fragments 16 VGPRs;
 //   * O^T(d block) += V8^T . P8^T: ONE MFMA per d block and tile (4 in bf16); P is packed to e4m3 straight from
 //     the accumulator registers (P <= 2^8 by the defer-max threshold, inside e4m3's range);
-//   * K and V tiles are 8 KiB each: half the LDS and global traffic.
+//   * K and V tiles are 8 KiB each: half the LDS and global traffic;
+//   * (round 2) the S accumulators hold the softmax exponent itself: sq is chosen so that softmax_scale log2(e) sq sk is a
+//     power of two, which the S MFMAs apply as their block scale, and -m (stale until a tile's row sum passes 2^8) is the
+//     C operand of a chain's first MFMA: the vector segment is exp2, add, pack - no fma, no max, no select (82 vector
+//     instructions per tile and wave, was ~180).  The sweep is then bound by LDS reads: 8 waves x 32 rows read every tile
+//     8 times, 128 KiB per tile and CU (a 4-wave, 64-row sweep like attn_v3_kernel would halve that; not built).
 #include "fp_common.h"
 
 // attn_fwd.hip: merge of the split tail items (same partial layout: O[256][128] unnormalised, m[256], l[256], fp32)
@@ -82,8 +87,10 @@ __global__ __launch_bounds__(256) void absmax_reduce_kernel(const float* __restr
     amax[i] = m;
 }
 
-// scales[0..H) = sq, [H..2H) = sk, [2H..2H+128H) = sv  (amax / 448; 1 where the amax is 0)
-__global__ __launch_bounds__(128) void scales_kernel(const float* __restrict__ amax, int heads,
+// scales[0..H) = sq, [H..2H) = sk, [2H..2H+128H) = sv  (amax / 448; 1 where the amax is 0).  sq is then raised (by a
+// factor below 2: e4m3 keeps its relative precision) so that c = softmax_scale * log2(e) * sq * sk is a power of two: the
+// sweep applies c as the MFMA's block scale and its accumulator holds the exponent of the softmax directly.
+__global__ __launch_bounds__(128) void scales_kernel(const float* __restrict__ amax, int heads, float scale_log2e,
                                                      float* __restrict__ scales) {
     __shared__ float red[2][2];
     const int h = blockIdx.x, d = threadIdx.x, C = heads * HD;
@@ -102,8 +109,11 @@ __global__ __launch_bounds__(128) void scales_kernel(const float* __restrict__ a
     if (d == 0) {
         mq = fmaxf(red[0][0], red[0][1]);
         mk = fmaxf(red[1][0], red[1][1]);
-        scales[h] = mq > 0.f ? mq * (1.f / FP8_MAX) : 1.f;
-        scales[heads + h] = mk > 0.f ? mk * (1.f / FP8_MAX) : 1.f;
+        const float sq = mq > 0.f ? mq * (1.f / FP8_MAX) : 1.f, sk = mk > 0.f ? mk * (1.f / FP8_MAX) : 1.f;
+        const float c = scale_log2e * sq * sk;
+        const float c2 = exp2f(ceilf(log2f(c)));                     // the next power of two (c itself if it is one)
+        scales[h] = sq * (c2 / c);
+        scales[heads + h] = sk;
     }
     scales[2 * heads + h * HD + d] = mv > 0.f ? mv * (1.f / FP8_MAX) : 1.f;
 }
@@ -198,6 +208,10 @@ __device__ __forceinline__ f32x16 mfma8(const i32x8 a, const i32x8 b, const f32x
     // cbsz = blgp = 0: both operands e4m3; scale operands 0 = unit block scales
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
 }
+// the same with block scale 2^(sa - 127) on the product (every lane's K block: the byte op_sel 0 picks), C added unscaled
+__device__ __forceinline__ f32x16 mfma8s(const i32x8 a, const i32x8 b, const f32x16 c, int sa) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, 127);
+}
 __device__ __forceinline__ float other_half(float x) {
     const unsigned u = __float_as_uint(x);
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
@@ -254,7 +268,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
         }
         return;
     }
-    const float c_log2 = scale_log2e * scales[head] * scales[heads + head];      // softmax scale x sq x sk
+    // softmax scale x log2(e) x sq x sk = 2^e exactly (scales_kernel): applied by the S MFMAs as their block scale
+    const int s_exp = 127 + (int)rintf(log2f(scale_log2e * scales[head] * scales[heads + head]));
 
     // Q fragments: d = 64 ks + 32 hh .. + 32 of query row r
     i32x8 qf[2];
@@ -303,7 +318,12 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
         for (int j = 0; j < 16; ++j) o_acc[d][j] = 0.f;
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x8 pf;
-    float m_run = -INFINITY, l_run = 0.f;
+    // The S accumulators hold the softmax exponent itself: S(t) = 2^e K.Q^T - m with -m as the C operand of a chain's
+    // first MFMA (negm: the value in all 16 registers; the lane is the query row).  m may be stale: it is moved only
+    // when a tile's P would leave e4m3's range - seen on the lane's partial row sum, limit 2^THR; the first tile's
+    // limit is -1, so it always takes that path and sets m to its true maximum.
+    float m_run = 0.f, l_run = 0.f, lim_cur = -1.f;
+    f32x16 negm = zero;
 
     // ---- prologue: K(0), V(0), K(1) into LDS; S(0)
     load_k();
@@ -317,8 +337,8 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-        s_acc[kb] = mfma8(rd_k(kbuf, kb, 0), qf[0], zero);
-        s_acc[kb] = mfma8(rd_k(kbuf, kb, 1), qf[1], s_acc[kb]);
+        s_acc[kb] = mfma8s(rd_k(kbuf, kb, 0), qf[0], negm, s_exp);
+        s_acc[kb] = mfma8s(rd_k(kbuf, kb, 1), qf[1], s_acc[kb], s_exp);
     }
     if (grp == 1) __builtin_amdgcn_s_barrier();
 
@@ -327,47 +347,63 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
         load_k();                               // K(t+2)  (clamped repeats past the end)
         load_v();                               // V(t+1)
         if (t0 + t == ntiles - 1 && (nkv & (KVBLK - 1))) {
-            const int valid = nkv - (t0 + t) * KVBLK;
+            int valid = nkv - (t0 + t) * KVBLK - 4 * hh;
+            asm volatile("" : "+v"(valid));     // (a real branch: if-converted, its 32 selects ran in every tile)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const int key = kb * 32 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-                    if (key >= valid) s_acc[kb][j] = -INFINITY;
-                }
-        }
-        float mx = s_acc[0][0];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s_acc[kb][j]);
-        mx = fmaxf(mx, other_half(mx)) * c_log2;
-        if (!__all(mx - m_run <= (float)THR_LOG2)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int j = 0; j < 16; ++j) o_acc[d][j] *= alpha;
+                for (int j = 0; j < 16; ++j)
+                    if (kb * 32 + (j & 3) + 8 * (j >> 2) >= valid) s_acc[kb][j] = -INFINITY;
+            asm volatile("" : "+v"(s_acc[0]), "+v"(s_acc[1]));      // (the masked values are made in here)
         }
         float rs = 0.f;
+        auto probs = [&]() __attribute__((always_inline)) {
+            rs = 0.f;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float p[4];
+                for (int g = 0; g < 4; ++g) {
+                    float p[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    p[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s_acc[kb][4 * g + j], c_log2, -m_run));
-                    rs += p[j];
+                    for (int j = 0; j < 4; ++j) {
+                        p[j] = __builtin_amdgcn_exp2f(s_acc[kb][4 * g + j]);
+                        rs += p[j];
+                    }
+                    int wd = 0;
+                    wd = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], wd, false);
+                    wd = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], wd, true);
+                    pf[kb * 4 + g] = wd;
                 }
-                int wd = 0;
-                wd = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], wd, false);
-                wd = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], wd, true);
-                pf[kb * 4 + g] = wd;
+        };
+        probs();
+        if (__builtin_amdgcn_ballot_w64(!(rs <= lim_cur)) != 0) {      // (uniform) the max grew past 2^THR, or t == 0
+            const bool first = t == 0;
+            lim_cur = __builtin_ldexpf(1.f, THR_LOG2);
+            float mx = s_acc[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s_acc[kb][j]);
+            mx = fmaxf(mx, other_half(mx));
+            // the accumulators hold s - m: the row's max has grown by mx (if positive); rows that did not grow keep m
+            const float delta = first ? mx : fmaxf(mx, 0.f);
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+            l_run *= alpha;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) negm[j] = -m_run;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) s_acc[kb][j] -= delta;
+            if (!first) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o_acc[d][j] *= alpha;
             }
+            probs();
+        }
         l_run += rs;
 
         __builtin_amdgcn_sched_barrier(0);
@@ -392,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void attn_fp8_kernel(const unsigned char* _
                     o_acc[g] = mfma8(fa[g % 3], pf, o_acc[g]);
                 } else {
                     const int kb = (g - 4) >> 1, ks = (g - 4) & 1;
-                    s_acc[kb] = mfma8(fa[g % 3], qf[ks], ks == 0 ? zero : s_acc[kb]);
+                    s_acc[kb] = mfma8s(fa[g % 3], qf[ks], ks == 0 ? negm : s_acc[kb], s_exp);
                 }
                 if (g == 2) {
                     if (t + 2 < nt) write_k(t & 1);
@@ -503,7 +539,7 @@ extern "C" int fp_attn_fwd_fp8_varlen(const void* q, const void* k, const void* 
     FP_CHECK_LAUNCH();
     absmax_reduce_kernel<<<dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, st>>>(partial, nblk, 3 * C, amax);
     FP_CHECK_LAUNCH();
-    scales_kernel<<<dim3((unsigned)heads), dim3(128), 0, st>>>(amax, heads, scales);
+    scales_kernel<<<dim3((unsigned)heads), dim3(128), 0, st>>>(amax, heads, softmax_scale * 1.4426950408889634f, scales);
     FP_CHECK_LAUNCH();
     quant_qk_kernel<<<dim3(2048), dim3(256), 0, st>>>((const bf16*)q, (const bf16*)k, q_row_stride, k_row_stride, S, heads,
                                                       scales, q8, k8);

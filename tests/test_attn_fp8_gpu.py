@@ -39,6 +39,10 @@ def dequantised(q, k, v, heads):
     sk = kh.abs().amax(dim=(0, 2), keepdim=True) * (1.0 / 448.0)
     sv = v.float().abs().amax(dim=0, keepdim=True) * (1.0 / 448.0)
     sq, sk, sv = (torch.where(s > 0, s, torch.ones_like(s)) for s in (sq, sk, sv))
+    # sq is raised (by a factor below 2) so that softmax_scale * log2(e) * sq * sk is a power of two: the kernel applies
+    # it as the MFMA's block scale (attn_fp8.hip, scales_kernel)
+    c = (sq * sk * (1.4426950408889634 / math.sqrt(128.0))).float()
+    sq = sq * (torch.exp2(torch.ceil(torch.log2(c))) / c)
     dq = ((qh * (1.0 / sq)).to(E4).float() * sq).view(S, -1)
     dk = ((kh * (1.0 / sk)).to(E4).float() * sk).view(S, -1)
     dv = (v.float() / sv).to(E4).float() * sv
