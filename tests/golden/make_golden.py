@@ -12,6 +12,8 @@ What is pinned by what:
   * fp8.npz                  <- utils/fp8_optimization_utils.py (imports as is).
   * lora.npz                 <- utils/lora_utils.py (imports as is): the three LoRA layouts merged into seeded
                                  state dicts (inputs rebuilt in the test by tests/lora_cases.py).
+  * pipeline.npz             <- diffusers_helper/pipelines/k_diffusion_hunyuan.py: sample_hunyuan end to end with the stub
+                                 transformer of tests/pipeline_cases.py (imports utils.py: see utils.npz).
   * utils.npz                <- diffusers_helper/utils.py: soft_append_bcthw, crop_or_pad_yield_mask,
                                  repeat_to_batch_size.  The module's top-level `import cv2` / `import torchvision` name
                                  packages this image lacks; two EMPTY module objects stand in for them during the import
@@ -306,7 +308,34 @@ def gen_utils():
     print("utils.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- the sampling pipeline
+def gen_pipeline():
+    """sample_hunyuan of the reference (noise draw, sigma schedule, CFG packing, UniPC) on tests/pipeline_cases.py.  The
+    module imports diffusers_helper/utils.py: same two empty stand-in modules as gen_utils."""
+    import types
+    for name in ("cv2", "torchvision"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    from diffusers_helper.pipelines import k_diffusion_hunyuan as ref_pipe
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import pipeline_cases as PC
+    out = {}
+    for i, (name, kw) in enumerate(PC.cases().items()):
+        steps = []
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            res = ref_pipe.sample_hunyuan(transformer=PC.StubTransformer(), generator=torch.Generator().manual_seed(40 + i),
+                                          callback=lambda d: steps.append(d["denoised"].float().clone().numpy()), **kw)
+        out[f"{name}/result"] = res.float().numpy()
+        out[f"{name}/denoised"] = np.stack(steps)
+    for n in (1, 1024, 14400, 100000):
+        out[f"mu/{n}"] = np.array([ref_pipe.calculate_flux_mu(n, exp_max=7.0)])
+    out["sigmas/25_mu1.2"] = ref_pipe.get_flux_sigmas_from_mu(25, 1.2).numpy()
+    np.savez_compressed(os.path.join(HERE, "pipeline.npz"), **out)
+    print("pipeline.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    gen_pipeline()
     gen_utils()
     gen_rope()
     gen_sampler()

@@ -76,3 +76,25 @@ def test_sample_hunyuan_plumbing_with_stub_transformer():
     assert calls[0][0] == 1000.0 and "latent_indices" in calls[0][1] and "guidance" in calls[0][1]
     want = torch.randn((1, 16, 3, 8, 8), generator=torch.Generator("cpu").manual_seed(31337))
     assert torch.isfinite(out).all() and want.shape == out.shape
+
+
+def test_sample_hunyuan_matches_the_reference_pipeline(golden_dir):
+    """tests/golden/pipeline.npz: the REFERENCE's sample_hunyuan (k_diffusion_hunyuan.py:27-124) run end to end on the
+    seeded cases and the stub transformer of tests/pipeline_cases.py - noise draw, flux-shift schedule, image-to-image
+    blend, batch repetition, CFG with rescale, extra / negative kwargs, the UniPC steps and their callback.  The first
+    three steps' denoised estimates (noise, schedule, argument packing, k-model, first-order updates) must be the same
+    BITS; from the third step on the mirror sums the two UniPC history terms as plain weighted sums where the reference
+    calls tensordot (sampler.py), which moves the last bit: same tolerance as the trajectory test above."""
+    import pipeline_cases as PC
+    P = np.load(os.path.join(golden_dir, "pipeline.npz"))
+    for i, (name, kw) in enumerate(PC.cases().items()):
+        steps = []
+        res = S.sample_hunyuan(transformer=PC.StubTransformer(), generator=torch.Generator().manual_seed(40 + i),
+                               callback=lambda d: steps.append(d["denoised"].float().clone().numpy()), **kw)
+        got, want = np.stack(steps), P[f"{name}/denoised"]
+        assert got.shape == want.shape and np.array_equal(got[:3], want[:3]), name
+        torch.testing.assert_close(torch.from_numpy(got), torch.from_numpy(want), rtol=2e-5, atol=2e-6)
+        torch.testing.assert_close(res.float(), torch.from_numpy(P[f"{name}/result"]), rtol=2e-5, atol=2e-6)
+    for n in (1, 1024, 14400, 100000):
+        assert S.calculate_flux_mu(n, exp_max=7.0) == float(P[f"mu/{n}"][0])
+    assert np.array_equal(S.get_flux_sigmas_from_mu(25, 1.2).numpy(), P["sigmas/25_mu1.2"])
