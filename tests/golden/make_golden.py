@@ -12,6 +12,8 @@ What is pinned by what:
   * fp8.npz                  <- utils/fp8_optimization_utils.py (imports as is).
   * lora.npz                 <- utils/lora_utils.py (imports as is): the three LoRA layouts merged into seeded
                                  state dicts (inputs rebuilt in the test by tests/lora_cases.py).
+  * hunyuan.npz              <- diffusers_helper/hunyuan.py: vae_decode_fake and the vae_decode / vae_encode wrappers on
+                                 a stub VAE (the module's diffusers import, a prompt template, is met by an empty dict).
   * pipeline.npz             <- diffusers_helper/pipelines/k_diffusion_hunyuan.py: sample_hunyuan end to end with the stub
                                  transformer of tests/pipeline_cases.py (imports utils.py: see utils.npz).
   * utils.npz                <- diffusers_helper/utils.py: soft_append_bcthw, crop_or_pad_yield_mask,
@@ -334,7 +336,33 @@ def gen_pipeline():
     print("pipeline.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- VAE entry points of the worker
+def gen_hunyuan():
+    """diffusers_helper/hunyuan.py: vae_decode_fake (the preview projection) and the vae_decode / vae_encode wrappers
+    (scaling factor, image_mode's per-frame decode) on the stub VAE of tests/utils_cases.py.  The module's one diffusers
+    import (a prompt template the prompt encoder uses; out of scope, never called) is met by an empty dict."""
+    import types
+    name = "diffusers.pipelines.hunyuan_video.pipeline_hunyuan_video"
+    parts = name.split(".")
+    for i in range(2, len(parts) + 1):
+        sys.modules.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+    sys.modules[name].DEFAULT_PROMPT_TEMPLATE = {}
+    from diffusers_helper import hunyuan as ref_h
+    UC = utils_cases()
+    out = {}
+    for cname, z in UC.preview_cases().items():
+        out[f"fake/{cname}"] = ref_h.vae_decode_fake(z).float().numpy()
+    vae = UC.StubVAE()
+    z = UC.preview_cases()["f32"]
+    out["decode/video"] = ref_h.vae_decode(z, vae).float().numpy()
+    out["decode/image_mode"] = ref_h.vae_decode(z, vae, image_mode=True).float().numpy()
+    out["encode"] = ref_h.vae_encode(UC.stub_image(), vae).float().numpy()
+    np.savez_compressed(os.path.join(HERE, "hunyuan.npz"), **out)
+    print("hunyuan.npz", len(out), "arrays")
+
+
 if __name__ == "__main__":
+    gen_hunyuan()
     gen_pipeline()
     gen_utils()
     gen_rope()

@@ -164,3 +164,19 @@ def test_repeat_to_batch_size_bit_identical_to_the_reference():
         else:
             assert np.array_equal(repeat_to_batch_size(x, b).numpy(), G[f"repeat/{name}"]), name
     assert repeat_to_batch_size(None, 3) is None
+
+
+def test_vae_entry_points_bit_identical_to_the_reference(golden_dir):
+    """tests/golden/hunyuan.npz: the reference's diffusers_helper/hunyuan.py - vae_decode_fake (latent -> RGB preview)
+    and the vae_decode / vae_encode wrappers (scaling factor, image_mode) on the stub VAE of tests/utils_cases.py."""
+    import os
+    import utils_cases as UC
+    from framepack_amd.vae import vae_decode, vae_decode_fake, vae_encode
+    G = np.load(os.path.join(golden_dir, "hunyuan.npz"))
+    for name, z in UC.preview_cases().items():
+        got = vae_decode_fake(z)
+        assert got.dtype == z.dtype and np.array_equal(got.float().numpy(), G[f"fake/{name}"]), name
+    vae, z = UC.StubVAE(), UC.preview_cases()["f32"]
+    assert np.array_equal(vae_decode(z, vae).float().numpy(), G["decode/video"])
+    assert np.array_equal(vae_decode(z, vae, image_mode=True).float().numpy(), G["decode/image_mode"])
+    assert np.array_equal(vae_encode(UC.stub_image(), vae).float().numpy(), G["encode"])

@@ -44,3 +44,43 @@ def repeat_cases():
         "times_2_of_2": (_randn(33, (2, 5)), 4),
         "uneven": (_randn(34, (2, 5)), 3),
     }
+
+
+def preview_cases():
+    """name -> latents [B, 16, T, H, W] for vae_decode_fake / the vae_decode wrappers."""
+    return {"f32": _randn(41, (1, 16, 3, 5, 4)) * 2.0, "bf16": (_randn(42, (2, 16, 1, 2, 3)) * 2.0).to(torch.bfloat16),
+            "f16": (_randn(43, (1, 16, 2, 2, 2)) * 3.0).to(torch.float16)}
+
+
+def stub_image():
+    return _randn(44, (1, 3, 1, 8, 8))
+
+
+class StubVAE:
+    """Duck-typed stand-in for AutoencoderKLHunyuanVideo in the vae_decode / vae_encode wrappers: `decode` turns a
+    latent [B,16,T,H,W] into 'frames' [B,3,4(T-1)+1,H,W] by a fixed formula that mixes time (so image_mode's per-frame
+    decode differs from the video decode), `encode` returns a distribution whose sample is a fixed function."""
+    device = torch.device("cpu")
+    dtype = torch.float32
+
+    class config:
+        scaling_factor = 0.476986
+
+    def decode(self, z):
+        t = z.shape[2]
+        frames = z[:, :3].repeat_interleave(4, dim=2)[:, :, 3:] if t > 1 else z[:, :3]
+        frames = frames + 0.1 * z[:, 3:6].mean(dim=2, keepdim=True)
+
+        class Out:
+            sample = frames * 0.5 + 0.25
+        return Out()
+
+    def encode(self, x):
+        class Dist:
+            @staticmethod
+            def sample():
+                return torch.tanh(x.mean(dim=1, keepdim=True)).expand(-1, 16, -1, -1, -1) * 1.5
+
+        class Out:
+            latent_dist = Dist()
+        return Out()
