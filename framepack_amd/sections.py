@@ -11,7 +11,7 @@ semantics; the two heavy calls are injected (`sample_fn` = framepack_amd.sampler
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Callable, Dict, List, Optional
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 
@@ -75,6 +75,27 @@ def crop_or_pad_yield_mask(x: torch.Tensor, length: int):
     y = x.new_zeros((B, length, C))
     y[:, :F] = x
     return y, mask
+
+
+# (height, width) buckets of ~640^2 pixels, ref diffusers_helper/bucket_tools.py:2-17 (data of the reference).  There is no
+# square one: a square input lands on (640, 608), the later of the two equally near entries.
+_BUCKETS_640 = tuple(zip((416, 448, 480, 512, 544, 576, 608, 640, 672, 704, 768, 832, 864, 960),
+                         (960, 864, 832, 768, 704, 672, 640, 608, 576, 544, 512, 480, 448, 416)))
+
+
+def find_nearest_bucket(h: int, w: int, resolution: int = 640) -> Tuple[int, int]:
+    """ref diffusers_helper/bucket_tools.py:42-79: the bucket whose aspect is nearest to h : w (cross-product distance
+    |h bw - w bh|; of equally near ones the LAST in table order), the table scaled by resolution / 640 and truncated
+    (the reference's precomputed 320 table is that same rule)."""
+    scale = resolution / 640.0
+    best, best_metric = None, float("inf")
+    for bh, bw in _BUCKETS_640:
+        if resolution != 640:
+            bh, bw = int(bh * scale), int(bw * scale)
+        metric = abs(h * bw - w * bh)
+        if metric <= best_metric:
+            best, best_metric = (bh, bw), metric
+    return best
 
 
 def pick_ui_section(i_section: int, keys, total_sections: int):

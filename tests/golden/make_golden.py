@@ -12,6 +12,7 @@ What is pinned by what:
   * fp8.npz                  <- utils/fp8_optimization_utils.py (imports as is).
   * lora.npz                 <- utils/lora_utils.py (imports as is): the three LoRA layouts merged into seeded
                                  state dicts (inputs rebuilt in the test by tests/lora_cases.py).
+  * buckets.npz              <- diffusers_helper/bucket_tools.py (imports as is): find_nearest_bucket over a size sweep.
   * hunyuan.npz              <- diffusers_helper/hunyuan.py: vae_decode_fake and the vae_decode / vae_encode wrappers on
                                  a stub VAE (the module's diffusers import, a prompt template, is met by an empty dict).
   * pipeline.npz             <- diffusers_helper/pipelines/k_diffusion_hunyuan.py: sample_hunyuan end to end with the stub
@@ -361,7 +362,20 @@ def gen_hunyuan():
     print("hunyuan.npz", len(out), "arrays")
 
 
+# ----------------------------------------------------------------------------- resolution buckets
+def gen_buckets():
+    """diffusers_helper/bucket_tools.py (imports as is): find_nearest_bucket over a sweep of sizes and resolutions."""
+    from diffusers_helper import bucket_tools as ref_b
+    UC = utils_cases()
+    q = UC.bucket_queries()
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = np.array([ref_b.find_nearest_bucket(h, w, resolution=r) for h, w, r in q], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "buckets.npz"), queries=np.array(q, dtype=np.int64), buckets=got)
+    print("buckets.npz", got.shape)
+
+
 if __name__ == "__main__":
+    gen_buckets()
     gen_hunyuan()
     gen_pipeline()
     gen_utils()

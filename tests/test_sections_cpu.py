@@ -180,3 +180,16 @@ def test_vae_entry_points_bit_identical_to_the_reference(golden_dir):
     assert np.array_equal(vae_decode(z, vae).float().numpy(), G["decode/video"])
     assert np.array_equal(vae_decode(z, vae, image_mode=True).float().numpy(), G["decode/image_mode"])
     assert np.array_equal(vae_encode(UC.stub_image(), vae).float().numpy(), G["encode"])
+
+
+def test_find_nearest_bucket_matches_the_reference(golden_dir):
+    """tests/golden/buckets.npz: the reference's bucket_tools.find_nearest_bucket over 363 (h, w, resolution) queries
+    (ties, both orientations, the precomputed 640 / 320 tables and scaled ones)."""
+    import os
+    import utils_cases as UC
+    G = np.load(os.path.join(golden_dir, "buckets.npz"))
+    q = UC.bucket_queries()
+    assert np.array_equal(np.array(q, dtype=np.int64), G["queries"])
+    got = np.array([S.find_nearest_bucket(h, w, resolution=r) for h, w, r in q], dtype=np.int64)
+    assert np.array_equal(got, G["buckets"])
+    assert S.find_nearest_bucket(640, 640) == (640, 608)        # no square bucket: the later of the two nearest wins

@@ -84,3 +84,14 @@ class StubVAE:
         class Out:
             latent_dist = Dist()
         return Out()
+
+
+def bucket_queries():
+    """(h, w, resolution) sweep for find_nearest_bucket: squares, both orientations, extreme aspects, ties, the
+    precomputed resolutions (640, 320) and scaled ones."""
+    import random
+    rnd = random.Random(5)
+    q = [(h, w, r) for r in (640, 320, 480, 512, 416, 720, 1024)
+         for h, w in ((1, 1), (640, 640), (1080, 1920), (1920, 1080), (100, 1000), (1000, 100), (607, 641), (3, 4), (768, 512))]
+    q += [(rnd.randint(1, 4000), rnd.randint(1, 4000), rnd.choice((640, 320, 352, 544, 608))) for _ in range(300)]
+    return q
