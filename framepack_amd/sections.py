@@ -157,8 +157,10 @@ def generate_sections(sample_fn: Callable, decode_fn: Optional[Callable], start_
         kw = dict(clean_latents=torch.cat([clean_pre, clean_post], dim=2), clean_latents_2x=clean_2x,
                   clean_latents_4x=clean_4x, **idx)
         frames = num_frames
-        if one_frame_inference:                                                   # ref :468-481
-            kw["clean_latents_2x"] = kw["clean_latents_4x"] = None
+        if one_frame_inference:
+            # ref :468-481 clears the 2x / 4x indices AND latents, but :503-505 then takes the latents from the history
+            # again: the sampler is handed 2x / 4x latents WITHOUT indices (tests/golden/worker.npz, case one_frame),
+            # which the transformer ignores (both must be there, hunyuan_video_packed.py:844, 858).  Same here.
             frames = 1
         generated = sample_fn(width=width, height=height, frames=frames, generator=rnd, **kw, **per_section)
         if is_last and not one_frame_inference:                                   # ref :655-656

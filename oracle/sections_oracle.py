@@ -2,8 +2,9 @@
 
 Written independently of framepack_amd/sections.py, from ref: framepack/worker.py:337-350 (padding schedule),
 :463-465 (index layout), :655-664 / :703-720 (history and decode windows), diffusers_helper/utils.py:64-75
-(cross-fade).  Pinned by the values SURVEY.md 8 quotes from the reference (indices of the last section at
-window 9) and by closed forms (frame counts); the reference module itself cannot be imported (gradio, cv2)."""
+(cross-fade).  Pinned by tests/golden/worker.npz - what the reference's own worker() handed to its sampler, decoder and
+video writer when run with recording stand-ins for those (tests/golden/make_worker_golden.py): padding schedule, index
+layout and frame counts here, the whole loop in framepack_amd/sections.py (tests/test_sections_cpu.py)."""
 from __future__ import annotations
 
 import numpy as np

@@ -52,6 +52,7 @@ def _stubs(calls):
                   clean_latents_2x, clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices, **kw):
         T = (frames + 3) // 4
         calls.append(dict(T=T, latent_indices=latent_indices[0].tolist(), clean=clean_latents.clone(),
+                          idx_2x=clean_latent_2x_indices, idx_4x=clean_latent_4x_indices,
                           two=None if clean_latents_2x is None else clean_latents_2x.clone(),
                           four=None if clean_latents_4x is None else clean_latents_4x.clone()))
         return torch.full((1, 16, T, height // 8, width // 8), float(len(calls)))
@@ -90,7 +91,10 @@ def test_one_frame_inference_path():
     calls = []
     sample_fn, decode_fn = _stubs(calls)
     res = S.generate_sections(sample_fn, decode_fn, torch.zeros(1, 16, 1, 4, 4), 32, 32, 7, one_frame_inference=True)
-    assert len(calls) == 1 and calls[0]["T"] == 1 and calls[0]["two"] is None and calls[0]["latent_indices"] == [9]
+    # one frame: no 2x / 4x INDICES (the latents themselves are still handed over, as the reference does; the
+    # transformer needs both to use them)
+    assert len(calls) == 1 and calls[0]["T"] == 1 and calls[0]["latent_indices"] == [9]
+    assert calls[0]["idx_2x"] is None and calls[0]["idx_4x"] is None and calls[0]["two"] is not None
     assert res.total_generated_latent_frames == 1 and res.history_pixels.shape[2] == 1
 
 
@@ -193,3 +197,76 @@ def test_find_nearest_bucket_matches_the_reference(golden_dir):
     got = np.array([S.find_nearest_bucket(h, w, resolution=r) for h, w, r in q], dtype=np.int64)
     assert np.array_equal(got, G["buckets"])
     assert S.find_nearest_bucket(640, 640) == (640, 608)        # no square bucket: the later of the two nearest wins
+
+
+# ---- the section loop against the REFERENCE's own worker: tests/golden/worker.npz holds what framepack/worker.py handed
+#      to its sampler / decoder / video writer when run on the cases of tests/worker_cases.py with recording stand-ins for
+#      those collaborators (tests/golden/make_worker_golden.py).  The same stand-ins are driven here by generate_sections.
+def _replay(case):
+    import worker_cases as WC
+    H, W = case["image_hw"]
+    h, w = S.find_nearest_bucket(H, W, resolution=640 if case.get("resolution_scale") == "Full (1x)" else 320)
+    encodes = [WC.stub_encode_hw(0, h // 8, w // 8)]
+
+    def prompt_kwargs(text):
+        vec, pool = WC.stub_prompt(text)
+        vec, mask = S.crop_or_pad_yield_mask(vec, length=512)
+        return dict(prompt_embeds=vec, prompt_embeds_mask=mask, prompt_poolers=pool)
+
+    section_latents, section_kwargs = {}, {}
+    for num, has_img, text in case.get("ui", []):
+        if has_img:
+            encodes.append(WC.stub_encode_hw(len(encodes), h // 8, w // 8))
+            section_latents[num] = encodes[-1]
+        # a UI row without a prompt falls back to the default prompt (worker.py:372-373), it does not look further back
+        section_kwargs[num] = prompt_kwargs(text) if text.strip() else {}
+    rec = dict(samples=[], decodes=[])
+
+    def decode_fn(lat):
+        rec["decodes"].append(lat.clone())
+        return WC.stub_decode(lat)
+
+    res = S.generate_sections(lambda **kw: WC.stub_sample(rec, **kw), decode_fn, encodes[0], h, w, case["sections"],
+                              latent_window_size=case["window"], seed=case["seed"],
+                              one_frame_inference=case.get("one_frame", False), section_latents=section_latents or None,
+                              sample_kwargs=prompt_kwargs("a prompt"), section_sample_kwargs=section_kwargs or None)
+    return rec, res, len(encodes)
+
+
+def test_section_loop_hands_over_what_the_reference_worker_does(golden_dir):
+    import os
+    import worker_cases as WC
+    G = np.load(os.path.join(golden_dir, "worker.npz"))
+    for name, case in WC.cases().items():
+        rec, res, n_enc = _replay(case)
+        assert len(rec["samples"]) == int(G[f"{name}/n_sections"][0]), name
+        assert len(rec["decodes"]) == int(G[f"{name}/n_decodes"][0]) and n_enc == int(G[f"{name}/encodes"][0]), name
+        for i, s in enumerate(rec["samples"]):
+            for k, v in s.items():
+                want = G[f"{name}/sample{i}/{k}"]
+                assert v.shape == want.shape and np.array_equal(v, want), (name, i, k)
+        for i, d in enumerate(rec["decodes"]):                 # which latent frames are decoded, bit for bit
+            assert np.array_equal(WC.sub(d), G[f"{name}/decode{i}"]), (name, i)
+        assert [s["pixel_frames"] for s in res.sections] == G[f"{name}/pixel_frames"].tolist(), name
+        assert np.array_equal(WC.sub(res.history_pixels), G[f"{name}/pixels"]), name
+
+
+def test_sections_oracle_is_pinned_by_the_reference_worker_too(golden_dir):
+    """oracle/sections_oracle.py (the independent restatement the GPU composition test checks against): its padding
+    schedule and index layout against what the reference's worker handed to its sampler (tests/golden/worker.npz)."""
+    import os
+    import worker_cases as WC
+    G = np.load(os.path.join(golden_dir, "worker.npz"))
+    for name, case in WC.cases().items():
+        if case.get("one_frame"):
+            continue                                   # (the oracle restates the video mode)
+        pads = SO.paddings(case["sections"])
+        assert len(pads) == int(G[f"{name}/n_sections"][0]), name
+        for i, pad in enumerate(pads):
+            ix = SO.indices(pad, case["window"])
+            for mine, theirs in (("latent", "latent_indices"), ("clean", "clean_latent_indices"),
+                                 ("two", "clean_latent_2x_indices"), ("four", "clean_latent_4x_indices")):
+                assert ix[mine].tolist() == G[f"{name}/sample{i}/{theirs}"][0].tolist(), (name, i, mine)
+        # frame counts of the pixel history after every section: 4 (latent frames) - 3
+        frames = np.cumsum([case["window"] + (1 if p == 0 else 0) for p in pads]) * 4 - 3
+        assert frames.tolist() == G[f"{name}/pixel_frames"].tolist(), name
