@@ -49,3 +49,41 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
     }
 #undef FP_CASE
 }
+
+// The q | k | v projection of a double-stream block (epilogue 0) or the fused in-projection of a single-stream block
+// (epilogue 2: GELU from column gelu_from on) WITH K2 in its epilogue: per-head RMSNorm of the q and k columns and RoPE on
+// rows < rope_rows (gemm_w4.h, QkNormArgs) - bit-identical to fp_gemm_bf16 followed by fp_qk_rmsnorm_rope_bf16 on the same
+// buffers, one pass over q and k less.  q / k occupy output columns [qcol0, qcol0 + heads*128) / [kcol0, ...), both
+// multiples of 128.  Needs the 4-wave kernel's alignment (c 16-byte aligned, ldc % 8 == 0).
+extern "C" int fp_gemm_bf16_qknorm(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, void* c,
+                                   int64_t ldc, int M, int N, int K, int epilogue, int gelu_from, const void* wq,
+                                   const void* wk, const void* wq_txt, const void* wk_txt, const float* rope,
+                                   int rope_rows, int qcol0, int kcol0, int heads, int head_dim, float eps,
+                                   void* stream) {
+    using namespace fp_gemm;
+    int64_t a2_delta;
+    int k1 = 0;
+    if (int rc = check_dense(a, lda, nullptr, k1, w, ldw, bias, c, ldc, M, N, K, epilogue, gelu_from, nullptr, 0, nullptr,
+                             a2_delta))
+        return rc;
+    FP_REQUIRE(epilogue == 0 || epilogue == 2);
+    FP_REQUIRE(head_dim == 128 && heads > 0 && wq && wk);
+    const int width = heads * 128;
+    FP_REQUIRE(qcol0 >= 0 && kcol0 >= 0 && qcol0 % 128 == 0 && kcol0 % 128 == 0 && qcol0 + width <= N && kcol0 + width <= N);
+    FP_REQUIRE(qcol0 + width <= kcol0 || kcol0 + width <= qcol0);
+    FP_REQUIRE(rope_rows >= 0 && rope_rows <= M && (rope_rows == 0 || rope));
+    FP_REQUIRE(((uintptr_t)wq & 15) == 0 && ((uintptr_t)wk & 15) == 0 && ((uintptr_t)rope & 15) == 0);
+    FP_REQUIRE((!wq_txt || ((uintptr_t)wq_txt & 15) == 0) && (!wk_txt || ((uintptr_t)wk_txt & 15) == 0));
+    FP_REQUIRE(((uintptr_t)c & 15) == 0 && ldc % 8 == 0);
+    if (M == 0) return 0;
+    ConvGeom cg{};
+    cg.gm = N >= 16384 ? 2 : 8;
+    QkNormArgs qk{(const bf16*)wq, (const bf16*)wk, (const bf16*)wq_txt, (const bf16*)wk_txt, rope, rope_rows, qcol0, kcol0,
+                  width, eps};
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue == 0)
+        return launch_w4<bf16, 0, 0, bf16, 8, 1>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, nullptr, 0,
+                                                 nullptr, cg, st, nullptr, nullptr, qk);
+    return launch_w4<bf16, 2, 0, bf16, 8, 1>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, nullptr, 0,
+                                             nullptr, cg, st, nullptr, nullptr, qk);
+}

@@ -117,7 +117,17 @@ static_assert(lgkm_before(1, 0, 8) == 1 && lgkm_before(1, 3, 8) == 1 && lgkm_bef
 // tiles are not issued at all (compile-time: a run-time test per MFMA splits the loop into basic blocks and the
 // compiler then drains the memory counters at every join - measured, 20 % slower than doing the padding).  The
 // staging, the LDS reads and their slots are those of NT = 8.
-template <typename T, typename TO, int EPI, int AMODE, int NT = 8>
+// QKN kernels (the q | k | v and single-block in-projections): K2 - per-head RMSNorm of q and k, RoPE on the image rows,
+// ref hunyuan_video_packed.py:137-160, 566-585 - applied in the epilogue, where a wave's 128 output columns are exactly one
+// head and the row layout (16 lanes x 8 columns per row) is the layout norm_kernels.hip's K2 kernel works in: the same
+// arithmetic on the same bf16-rounded values, so the result is bit-identical to the separate pass, which is then not run.
+struct QkNormArgs {
+    const bf16 *wq, *wk, *wq_txt, *wk_txt;      // RMSNorm weights [128]; *_txt (may be null): rows >= rope_rows
+    const float* rope;                          // [rope_rows][cos 128 | sin 128]
+    int rope_rows, qcol0, kcol0, width;         // q / k occupy output columns [qcol0, +width) / [kcol0, +width)
+    float eps;
+};
+template <typename T, typename TO, int EPI, int AMODE, int NT = 8, int QKN = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A, int64_t lda, int64_t a2_delta,
                                                          int k1, const T* __restrict__ W, int64_t ldw,
                                                          const TO* __restrict__ bias, TO* __restrict__ C,
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                                                          const TO* __restrict__ R, int64_t ldr,
                                                          const TO* __restrict__ gate, int ntm, int ntn, ConvGeom cg,
                                                          const float* __restrict__ a_scale,
-                                                         const float* __restrict__ w_scale) {
+                                                         const float* __restrict__ w_scale, QkNormArgs qk) {
     typedef i32x4 frag_t;
     typedef TO Tx4 __attribute__((ext_vector_type(4)));
     constexpr bool SCALED = sizeof(T) == 1;
@@ -488,6 +498,20 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         const int lrow = el >> 4, lchk = el & 15;
         const int gcol = en0 + wc * ecw + lchk * 8;            // first of this lane's 8 columns in row layout
         const bool col_ok = gcol < N && lchk * 8 < ecw;        // N % 8 == 0: a chunk is inside or outside
+        // QKN: is this wave's column block a q head (0), a k head (1) or neither (-1)?  (uniform)
+        int qk_which = -1;
+        bf16x8 qk_w_img = {}, qk_w_txt = {};
+        if constexpr (QKN) {
+            const int c0 = __builtin_amdgcn_readfirstlane(en0 + wc * ecw);
+            if (c0 >= qk.qcol0 && c0 < qk.qcol0 + qk.width) qk_which = 0;
+            else if (c0 >= qk.kcol0 && c0 < qk.kcol0 + qk.width) qk_which = 1;
+            if (qk_which >= 0) {
+                const bf16* wi = qk_which ? qk.wk : qk.wq;
+                const bf16* wt = qk_which ? qk.wk_txt : qk.wq_txt;
+                qk_w_img = *reinterpret_cast<const bf16x8*>(wi + lchk * 8);
+                qk_w_txt = wt ? *reinterpret_cast<const bf16x8*>(wt + lchk * 8) : qk_w_img;
+            }
+        }
         static_for<8>([&](auto MI_) __attribute__((always_inline)) {
             constexpr int mi = MI_;
             unsigned char* sb = stage + (mi & 1) * 4096;
@@ -502,6 +526,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                 if (mi + 2 < 8) load_resid(em0, en0, ecw, mi + 2);
             }
             const float as = SCALED ? a_scale[min(mrow0 + fr, M - 1)] : 1.f;
+            // QKN: the four rows' cos | sin go out before the accumulators are converted (their latency is covered by it)
+            f32x4 qk_cs[QKN ? 4 : 1][4];
+            if constexpr (QKN) {
+                if (qk_which >= 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int m = mrow0 + lrow + 4 * i;
+                        if (m < qk.rope_rows) {
+                            const float* cs = qk.rope + (int64_t)m * 256 + lchk * 8;
+                            qk_cs[i][0] = *reinterpret_cast<const f32x4*>(cs);
+                            qk_cs[i][1] = *reinterpret_cast<const f32x4*>(cs + 4);
+                            qk_cs[i][2] = *reinterpret_cast<const f32x4*>(cs + 128);
+                            qk_cs[i][3] = *reinterpret_cast<const f32x4*>(cs + 132);
+                        }
+                    }
+                }
+            }
             static_for<8>([&](auto NI_) __attribute__((always_inline)) {
                 constexpr int ni = NI_;
                 if constexpr (ni >= NT) return;
@@ -534,7 +575,40 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = lrow + 4 * i;
-                const Tx8 ov = *reinterpret_cast<const Tx8*>(sb + row * 256 + ((lchk ^ row) << 4));
+                Tx8 ov = *reinterpret_cast<const Tx8*>(sb + row * 256 + ((lchk ^ row) << 4));
+                if constexpr (QKN) {
+                    // K2's arithmetic (norm_kernels.hip, qk_rmsnorm_rope_kernel), rounding point by rounding point
+                    if (qk_which >= 0) {
+                        const bool is_txt = mrow0 + row >= qk.rope_rows;
+                        const bf16x8 wv = is_txt ? qk_w_txt : qk_w_img;
+                        float f[8], ss = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            f[j] = (float)ov[j];
+                            ss += f[j] * f[j];
+                        }
+                        const float r = rsqrtf(group16_sum(ss) * (1.f / 128.f) + qk.eps);
+                        float nn[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const bf16 a = (bf16)(f[j] * r);
+                            nn[j] = (float)(bf16)((float)a * (float)wv[j]);
+                        }
+                        if (!is_txt) {
+                            const f32x4 c0 = qk_cs[i][0], c1 = qk_cs[i][1], s0 = qk_cs[i][2], s1 = qk_cs[i][3];
+                            const float c[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+                            const float sn[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+                            for (int p2 = 0; p2 < 4; ++p2) {
+                                ov[2 * p2] = (TO)(nn[2 * p2] * c[2 * p2] + (-nn[2 * p2 + 1]) * sn[2 * p2]);
+                                ov[2 * p2 + 1] = (TO)(nn[2 * p2 + 1] * c[2 * p2 + 1] + nn[2 * p2] * sn[2 * p2 + 1]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) ov[j] = (TO)nn[j];
+                        }
+                    }
+                }
                 if (col_ok && mrow0 + row < M) *reinterpret_cast<Tx8*>(C + (int64_t)(mrow0 + row) * ldc + gcol) = ov;
             }
         });
@@ -625,22 +699,22 @@ inline int persistent_grid() {
     return n;
 }
 
-template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8>
+template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8, int QKN = 0>
 int launch_w4(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
               void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
               const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
-              const float* w_scale = nullptr) {
+              const float* w_scale = nullptr, const QkNormArgs& qk = QkNormArgs{}) {
     // lane offsets inside a tile are 32-bit: 255 rows x the row stride in bytes has to fit
     if (lda >= (int64_t(1) << 22) || ldw >= (int64_t(1) << 22)) return (int)hipErrorInvalidValue;
     const int ntm = (M + BM - 1) / BM, ntn = (N + 32 * NT - 1) / (32 * NT);
     constexpr int smem = 2 * BUF_BYTES + 4 * 8192;        // operand buffers + the epilogue's row stage
-    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT>;
+    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT, QKN>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     kern<<<dim3((unsigned)min(ntm * ntn, persistent_grid())), dim3(256), smem, st>>>((const T*)a, lda, a2_delta, k1, (const T*)w, ldw,
                                                               (const TO*)bias, (TO*)c, ldc, M, N, K, gelu_from,
                                                               (const TO*)resid, ldr, (const TO*)gate, ntm, ntn, cg,
-                                                              a_scale, w_scale);
+                                                              a_scale, w_scale, qk);
     FP_CHECK_LAUNCH();
     return 0;
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     "fp_rel_l1_acc_floats": [],
     "fp_rel_l1_bf16": [P, P, L, P, P],
     "fp_gemm_bf16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
+    "fp_gemm_bf16_qknorm": [P, L, P, L, P, P, L, I, I, I, I, I, P, P, P, P, P, I, I, I, I, I, F, P],
     "fp_gemm_f16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_debug_gemm_variant": [I],
     "fp_debug_attn_variant": [I],

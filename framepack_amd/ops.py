@@ -312,6 +312,40 @@ def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
     return out
 
 
+def gemm_qknorm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, wq: torch.Tensor,
+                wk: torch.Tensor, rope: Optional[torch.Tensor], rope_rows: int, qcol0: int, kcol0: int, heads: int,
+                epilogue: int = EPI_BIAS, gelu_from: int = 0, eps: float = 1e-6, wq_txt: Optional[torch.Tensor] = None,
+                wk_txt: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K5 + K2 in one launch: out = epilogue(a @ weight.T + bias) with the per-head RMSNorm of the q and k columns
+    ([qcol0, +heads*128), [kcol0, +heads*128)) and RoPE on rows < rope_rows applied in the GEMM's epilogue - the same
+    bits as gemm(...) followed by qk_rmsnorm_rope_(...) on those column views.  bf16; out 16-byte aligned, row stride
+    % 8 == 0 (`gemm_qknorm_ok`)."""
+    _dev(a, weight, bias, out, wq, wk, rope, wq_txt, wk_txt)
+    a_, M, K1, lda = _rows2d(a)
+    w_, N, K, ldw = _rows2d(weight)
+    o_, Mo, No, ldc = _rows2d(out)
+    assert K1 == K and (Mo, No) == (M, N) and a.dtype == BF16 and weight.dtype == BF16 and out.dtype == BF16
+    assert bias is None or (bias.dtype == BF16 and bias.numel() == N)
+    assert epilogue in (EPI_BIAS, EPI_GELU_FROM) and gemm_qknorm_ok(out)
+    for w in (wq, wk, wq_txt, wk_txt):
+        assert w is None or (w.dtype == BF16 and w.numel() == 128 and w.is_contiguous())
+    if rope_rows > 0:
+        assert rope is not None and rope.dtype == torch.float32 and rope.is_contiguous()
+        assert rope.shape[-1] == 256 and rope.numel() >= rope_rows * 256
+    if M == 0:
+        return out
+    _lib.check(_lib.load().fp_gemm_bf16_qknorm(a_.data_ptr(), lda, w_.data_ptr(), ldw, _ptr(bias), o_.data_ptr(), ldc, M, N,
+                                               K, epilogue, gelu_from, wq.data_ptr(), wk.data_ptr(), _ptr(wq_txt),
+                                               _ptr(wk_txt), _ptr(rope), rope_rows, qcol0, kcol0, heads, 128, eps,
+                                               _stream(a)), "fp_gemm_bf16_qknorm")
+    return out
+
+
+def gemm_qknorm_ok(out: torch.Tensor) -> bool:
+    """The fused form runs on the 4-wave kernel only: output rows stored 16 bytes per lane."""
+    return out.dtype == BF16 and out.data_ptr() % 16 == 0 and out.stride(-2) % 8 == 0 and out.stride(-1) == 1
+
+
 # ---- K6: fp8 linears on the fp8 MFMA (opt-in: e4m3 activations are outside the 1e-2 parity bar) -------------
 
 FP8 = torch.float8_e4m3fn

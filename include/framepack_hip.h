@@ -132,6 +132,18 @@ int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void*
                  const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
                  const void* resid, int64_t ldr, const void* gate, void* stream);
 
+/* K5 + K2 in one launch: the q | k | v projection of a double-stream block (hunyuan_video_packed.py:552-563,
+ * epilogue 0) or the fused in-projection of a single-stream block (:570-579, epilogue 2: tanh-GELU on columns >=
+ * gelu_from) with the per-head RMSNorm of q and k and the RoPE of the rows < rope_rows (:137-160, 581-585) applied in
+ * the GEMM's epilogue.  Bit-identical to fp_gemm_bf16 followed by fp_qk_rmsnorm_rope_bf16 on the same buffers (same
+ * arithmetic on the same bf16-rounded values), one pass over q and k less.  q / k are the output columns [qcol0, qcol0 +
+ * heads*128) / [kcol0, kcol0 + heads*128) (multiples of 128, disjoint); wq, wk, wq_txt, wk_txt, rope, rope_rows, eps
+ * as in fp_qk_rmsnorm_rope_bf16.  c 16-byte aligned, ldc % 8 == 0; the other arguments as fp_gemm_bf16. */
+int fp_gemm_bf16_qknorm(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, void* c,
+                        int64_t ldc, int M, int N, int K, int epilogue, int gelu_from, const void* wq, const void* wk,
+                        const void* wq_txt, const void* wk_txt, const float* rope, int rope_rows, int qcol0,
+                        int kcol0, int heads, int head_dim, float eps, void* stream);
+
 /* ---- K6: fp8 linears on the gfx950 fp8 MFMA ---------------------------------------------------------------
  * Replaces the patched nn.Linear.forward of utils/fp8_optimization_utils.py (fp8_linear_forward_patch: e4m3
  * weight * scale_weight, then F.linear) with a GEMM that multiplies in e4m3.  Opt-in: quantised activations move

@@ -356,3 +356,38 @@ def test_attention_split_last_round_matches_unsplit_sweeps(attn_variant):
         sl = slice(h * 128, (h + 1) * 128)
         p = torch.softmax(q[lo:hi, sl].float() @ k[:, sl].float().T / math.sqrt(128.0), dim=-1)
         assert rel_l2(o[lo:hi, sl], p @ v[:, sl].float()) < 5e-3, (h, lo)
+
+
+@pytest.mark.parametrize("layout", ["double_img", "double_txt", "single"])
+@pytest.mark.parametrize("M", [1, 300, 777])
+def test_gemm_with_k2_in_its_epilogue_is_bit_identical_to_the_two_passes(layout, M):
+    """fp_gemm_bf16_qknorm: the q | k | v projection (or the single block's in-projection with its GELU columns) with the
+    per-head RMSNorm and RoPE applied in the epilogue's row layout - the same arithmetic on the same bf16-rounded values
+    as fp_gemm_bf16 followed by fp_qk_rmsnorm_rope_bf16, so the outputs must be the same BITS."""
+    heads, K = 4, 256
+    d = heads * 128
+    g = torch.Generator().manual_seed(M + len(layout))
+    if layout == "single":
+        N, qcol0, kcol0, epi, gelu_from = 7 * d, 2 * d, 0, ops.EPI_GELU_FROM, 3 * d        # [k | v | q | mlp]
+        rope_rows = (2 * M) // 3
+        wq_txt = wk_txt = None
+    else:
+        N, qcol0, kcol0, epi, gelu_from = 3 * d, 0, d, ops.EPI_BIAS, 0                       # [q | k | v]
+        rope_rows = M if layout == "double_img" else 0
+        wq_txt, wk_txt = ((torch.randn(128, generator=g) * 0.2 + 1).to(BF).to(DEV) for _ in range(2))
+        if layout == "double_img":
+            wq_txt = wk_txt = None
+    a = torch.randn(M, K, generator=g).to(BF).to(DEV)
+    w = (torch.randn(N, K, generator=g) / 16).to(BF).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).to(BF).to(DEV)
+    wq, wk = ((torch.randn(128, generator=g) * 0.2 + 1).to(BF).to(DEV) for _ in range(2))
+    ang = torch.rand(max(rope_rows, 1), 128, generator=g) * 6.28
+    rope = torch.cat([torch.cos(ang), torch.sin(ang)], dim=1).contiguous().to(DEV)
+    want = ops.gemm(a, w, b, epilogue=epi, gelu_from=gelu_from)
+    ops.qk_rmsnorm_rope_(want[:, qcol0:qcol0 + d], want[:, kcol0:kcol0 + d], wq, wk, rope, rope_rows, heads,
+                         wq_txt=wq_txt, wk_txt=wk_txt)
+    got = torch.full((M, N), float("nan"), dtype=BF, device=DEV)
+    ops.gemm_qknorm(a, w, b, got, wq, wk, rope, rope_rows, qcol0, kcol0, heads, epilogue=epi, gelu_from=gelu_from,
+                    wq_txt=wq_txt, wk_txt=wk_txt)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
