@@ -342,6 +342,9 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         # text stream of the double blocks on a low-priority side stream (_double_block); FRAMEPACK_TEXT_OVERLAP=0: off
         self.text_stream_overlap = os.environ.get("FRAMEPACK_TEXT_OVERLAP", "1") != "0"
         self._side_streams = {}
+        # K2 (RMSNorm + RoPE of q, k) in the epilogue of the GEMM that produces them (_ln_lin_qk): bit-identical, but
+        # measured 0.8 % SLOWER per step than the separate pass, so off unless FRAMEPACK_FUSE_QK=1
+        self.fuse_qk_norm = os.environ.get("FRAMEPACK_FUSE_QK", "0") == "1"
         self.fp8_attention = False     # joint attention with e4m3 Q, K, P, V (enable_fp8_attention)
 
     # ---- reference API ---------------------------------------------------------------------
@@ -440,13 +443,14 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.fp8_attention = bool(enable)
         return self
 
-    def _qk_attend(self, q, k, v, wq, wk, rope, n_img, wq_txt=None, wk_txt=None):
+    def _qk_attend(self, q, k, v, wq, wk, rope, n_img, wq_txt=None, wk_txt=None, normed=False):
         """K2 (RMSNorm of q and k per head, RoPE on the image rows) and the joint attention over [image rows | text
         rows]; output written over q.  Under sequence parallelism K2 writes its results and v straight into the send
         buffer of the head exchange (q, k, v themselves stay raw: only the attention output lands in q)."""
         attn = ops.attention_fp8 if self.fp8_attention else ops.attention
         if self.sp_world == 1:
-            ops.qk_rmsnorm_rope_(q, k, wq, wk, rope, n_img, self.heads, wq_txt=wq_txt, wk_txt=wk_txt)
+            if not normed:                      # (normed: K2 was applied in the producing GEMM's epilogue, _ln_lin_qk)
+                ops.qk_rmsnorm_rope_(q, k, wq, wk, rope, n_img, self.heads, wq_txt=wq_txt, wk_txt=wk_txt)
             attn(q, k, v, self.heads, out=q)
         else:
             from .ulysses import pick_chunks, ulysses_attention
@@ -673,6 +677,22 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         aq, asc = ops.layernorm_modulate_fp8(x, sc, sh, out=ws.Q[:M * K].view(M, K), out_scale=ws.QS[:M])
         return ops.gemm_fp8(aq, asc, w[0], w[1], b, **kw)
 
+    def _fuse_qk(self, w, out) -> bool:
+        """K2 in the q | k | v GEMM's epilogue (ops.gemm_qknorm): one GPU, bf16 weights, output aligned for the 4-wave
+        kernel; off by default (`fuse_qk_norm`, FRAMEPACK_FUSE_QK=1: see __init__)."""
+        return (self.fuse_qk_norm and self.sp_world == 1 and not isinstance(w, tuple) and w.dtype == torch.bfloat16
+                and ops.gemm_qknorm_ok(out))
+
+    def _ln_lin_qk(self, ws, x, sc, sh, n, w, b, out, wq, wk, rope, rope_rows, qcol0, kcol0, **kw):
+        """_ln_lin for a projection whose output holds q and k: with K2 fused into the GEMM when `_fuse_qk` allows.
+        Returns whether q and k left the GEMM normalised."""
+        if not self._fuse_qk(w, out):
+            self._ln_lin(ws, x, sc, sh, n, w, b, out=out, **{k_: v_ for k_, v_ in kw.items() if k_ in ("epilogue", "gelu_from")})
+            return False
+        ops.layernorm_modulate(x, sc, sh, out=n)
+        ops.gemm_qknorm(n, w, b, out, wq, wk, rope, rope_rows, qcol0, kcol0, self.heads, **kw)
+        return True
+
     def _double_block(self, e, mod_i, mod_c, ws, Si, S, rope, side=None):
         """One double-stream block (ref :537-604).  The two streams meet only in the joint attention: everything else of
         the text stream (its rows of X, N, Y; its own weights) is independent of the image stream's.  With `side`
@@ -689,8 +709,11 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         Fh = Y[:, 3 * d:]
         GR = ops.EPI_GATE_RESIDUAL
 
-        def text_pre():
-            self._ln_lin(ws, X[Si:], csc_a, csh_a, N[Si:], e.w_qkv_c, e.b_qkv_c, out=qkv[Si:])
+        normed = [False, False]
+
+        def text_pre():                 # (text rows: their own norm weights, no RoPE)
+            normed[1] = self._ln_lin_qk(ws, X[Si:], csc_a, csh_a, N[Si:], e.w_qkv_c, e.b_qkv_c, qkv[Si:], e.nq_c, e.nk_c,
+                                        None, 0, 0, d)
 
         def text_post():
             self._lin(ws, q[Si:], e.w_out_c, e.b_out_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_a)
@@ -698,7 +721,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_m)
 
         main = torch.cuda.current_stream(X.device) if side is not None else None
-        self._ln_lin(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, out=qkv[:Si])
+        normed[0] = self._ln_lin_qk(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, qkv[:Si], e.nq, e.nk, rope, Si, 0, d)
         if side is None:
             text_pre()
         else:
@@ -706,7 +729,11 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                 text_pre()
                 side[1].record(side[0])
             main.wait_event(side[1])
-        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, wq_txt=e.nq_c, wk_txt=e.nk_c)
+        if normed[0] != normed[1]:          # (one stream fused, the other not: finish the other's K2 by itself)
+            lo, hi = (Si, S) if normed[0] else (0, Si)
+            ops.qk_rmsnorm_rope_(q[lo:hi], k[lo:hi], e.nq_c if normed[0] else e.nq, e.nk_c if normed[0] else e.nk,
+                                 None if normed[0] else rope, 0 if normed[0] else Si, H)
+        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, wq_txt=e.nq_c, wk_txt=e.nk_c, normed=normed[0] or normed[1])
         if side is not None:
             side[2].record(main)
             side[0].wait_event(side[2])
@@ -727,10 +754,10 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         shift, scale, gate = mod.chunk(3)
-        self._ln_lin(ws, X, scale, shift, N, e.w_in, e.b_in, out=Y, epilogue=ops.EPI_GELU_FROM,
-                     gelu_from=3 * d)                                                       # [k | v | q | gelu(mlp)]
+        normed = self._ln_lin_qk(ws, X, scale, shift, N, e.w_in, e.b_in, Y, e.nq, e.nk, rope, Si, 2 * d, 0,
+                                 epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)               # [k | v | q | gelu(mlp)]
         k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]
-        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si)
+        self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, normed=normed)
         self._lin(ws, Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
 
     def _text_side_stream(self, device):

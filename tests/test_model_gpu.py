@@ -406,3 +406,28 @@ def test_text_stream_on_the_side_stream_changes_nothing(tiny):
         assert torch.isfinite(got.float()).all() and torch.equal(got, want)
     del big
     torch.cuda.empty_cache()
+
+
+def test_k2_in_the_gemm_epilogue_changes_nothing(tiny):
+    """With `fuse_qk_norm` the q | k | v GEMMs of the blocks apply K2 (RMSNorm + RoPE of q and k) in their epilogue (model._ln_lin_qk): the
+    forward must return the same BITS as with the separate K2 pass - tiny model (head count 2: the q / k column ranges
+    are 256 wide), and 13B width with text rows and both block kinds."""
+    m, _ = tiny
+    assert not m.fuse_qk_norm            # off by default: bit-identical but measured slower (DESIGN.md section 4)
+    for case in ("config1", "odd_bucket_pad", "one_frame"):
+        kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES[case]))
+        m.fuse_qk_norm = False
+        want = m(return_dict=False, **kw)[0].clone()
+        m.fuse_qk_norm = True
+        assert torch.equal(m(return_dict=False, **kw)[0], want), case
+        m.fuse_qk_norm = False
+    cfg_kw = dict(synthetic.CONFIG_13B, num_layers=2, num_single_layers=2)
+    big, _ = build(cfg_kw, seed=3)
+    kw = to_dev(synthetic.make_inputs(dtype=BF, seed=12, frames_latent=5, height=320, width=256, n_text=200, sigma=0.4))
+    big.fuse_qk_norm = False
+    want = big(return_dict=False, **kw)[0].clone()
+    big.fuse_qk_norm = True
+    got = big(return_dict=False, **kw)[0]
+    assert torch.isfinite(got.float()).all() and torch.equal(got, want)
+    del big
+    torch.cuda.empty_cache()
