@@ -490,11 +490,16 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
 //   * S^T accumulates straight into VGPRs, and the first MFMA of each chain takes C = -m (a 16-register block per
 //     row block that holds the row's running max, negated): the accumulator IS s * scale * log2e - m, so a score costs
 //     one v_exp_f32, one v_add_f32 (row sum) and half a v_cvt_pk_bf16_f32 - no AGPR read, no fma;
-//   * no row max in the common case: P = exp2(s - m) is computed with the running max as it stands, and the packed
-//     bf16 P dwords are max-reduced two at a time (v_pk_maximum3_f16 on their bit patterns: non-negative bf16 order as
-//     their bits do).  Only when some P exceeds 2^THR - the row's max has grown by more than THR - is the tile redone
-//     on a slow path: true row max, m += growth, O and l rescaled, the tile's and the next tile's accumulators shifted,
-//     P recomputed.  The first tile always takes it (m starts at 0);
+//   * no row max in the common case: P = exp2(s - m) is computed with the running max as it stands, and the growth test
+//     rides on the row sums the softmax needs anyway: only when a tile's row sum exceeds 2^THR - some P did, the row's
+//     max has grown by more than THR - is the tile redone on a slow path: true row max, m += growth, O and l rescaled,
+//     the tile's and the next tile's accumulators shifted, P recomputed.  The first tile always takes it (its limit is
+//     -1; m starts at 0);
+//   * a lone wave per SIMD sends one instruction of any kind every ~4 cycles, and the vector ones are what the tile's
+//     time follows: the tile loop is split - steps whose K(t+3) / V(t+2) tiles lie wholly inside the segment load
+//     without the per-row clamp, by the BUFFER form of the LDS-DMA (lane term = loop-invariant offset register, tile term
+//     = scalar offset operand, piece = immediate, four pieces per m0 value): no vector instruction per piece; the clamped
+//     global form remains for the prologue, the last steps and short segments (389 -> 340 instructions per tile);
 //   * every LDS fragment read is inline asm with a counted lgkmcnt in front of its first MFMA, and the first three V^T
 //     fragments of the NEXT tile are requested behind this tile's last MFMAs (V runs two tiles ahead in a 4-slot ring,
 //     so that tile's V is known to have landed one barrier earlier): no LDS latency is exposed behind the barrier;
