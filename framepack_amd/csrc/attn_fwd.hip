@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
 //   iteration t:   MFMA stream   slots  0..31  O^T += V(t-1)^T . P(t-1)^T
 //                                slots 32..63  S^T(t+1) = K(t+1) . Q'^T - m      (into the VGPR set S(t) is not in)
 //                  other         slots  0..7   the 8 LDS-DMA pieces of K(t+3), V(t+2)
-//                                slots  8..63  64 exp2, 64 adds, 32 packs, 16 packed max3 (exp h behind MFMA 8 + 7h/8: the
+//                                slots  8..63  64 exp2, 64 adds, 32 packs (exp h behind MFMA 8 + 7h/8: the
 //                                              P^T fragment an item completes was consumed by slot 8 (h/16) + 7)
 //                                even slots    one fragment read (f + 3 while f is multiplied)
 // Timing-only builds (tools/attn_skip_probe.sh): -DFP_V3_SKIP=<mask> leaves one stream of the tile loop out (results are
