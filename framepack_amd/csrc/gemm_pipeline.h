@@ -51,6 +51,10 @@ constexpr int BUF_BYTES = 2 * OP_BYTES;      // A tile then W tile
 struct ConvGeom {
     int Ti, Hi, Wi, To, Ho, Wo, Cin, st, sh, sw, dt, dh, dw, hmax, wmax, gm;
     int lcin;      // log2(Cin) (gemm_w4.h's gather: Cin is a power of two there)
+    // gemm_w4.h, convolutions: walk the output row tiles band by band - a band = `band` consecutive tiles of a frame,
+    // taken through all To frames before the next band (`tf` = tiles per frame; 0 = frame after frame).  The three
+    // temporal taps of a band then find their input frames in the caches instead of one frame (> 100 MB) later.
+    int band, tf;
 };
 
 // OCP e4m3 storage type of the fp8 path (K6): one byte per element, so a 128-B LDS row holds 128 K values.

@@ -195,7 +195,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         const int first = group * GM;
         const int gsz = min(nmaj - first, GM);
         const int tmaj = first + in_group % gsz, tmin = in_group / gsz;
-        const int tm = cg.gm < 0 ? tmin : tmaj, tn = cg.gm < 0 ? tmaj : tmin;
+        int tm = cg.gm < 0 ? tmin : tmaj;
+        const int tn = cg.gm < 0 ? tmaj : tmin;
+        if (AMODE == 1 && cg.band > 0) {               // band-major walk (ConvGeom::band): position -> (band, frame, tile)
+            const int per = cg.band * cg.To, bnd = tm / per, rem = tm - bnd * per;
+            const int t = rem / cg.band;
+            tm = t * cg.tf + bnd * cg.band + (rem - t * cg.band);
+        }
         m0 = tm * BM;
         n0 = tn * (2 * CW);
 #pragma unroll

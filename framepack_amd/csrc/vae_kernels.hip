@@ -56,9 +56,29 @@ extern "C" int fp_gemm_f16_f32out(const void* a, int64_t lda, const void* w, int
                                        (hipStream_t)stream);
 }
 
-static int conv_launch(const void* x, const void* w, const void* bias, void* y, const fp_gemm::ConvGeom& cg, int Cout,
+// Band-major tile walk for a convolution over more than one frame (ConvGeom::band): bands of >= 16 row tiles (4 096
+// output voxels: about 1 MiB of a 128-channel input frame, three frames of it inside an XCD's 4 MiB L2) when a frame is
+// a whole number of tiles.  FRAMEPACK_CONV_BAND=0 keeps the frame-after-frame walk (diagnostics, read once).
+static void pick_band(fp_gemm::ConvGeom& cg) {
+    static const int mode = [] { const char* e = getenv("FRAMEPACK_CONV_BAND"); return e ? atoi(e) : -1; }();
+    cg.band = cg.tf = 0;
+    const int64_t frame = (int64_t)cg.Ho * cg.Wo;
+    if (mode == 0 || cg.To < 2 || frame % fp_gemm::BM != 0) return;
+    const int tf = (int)(frame / fp_gemm::BM);
+    const int want = mode > 0 ? mode : 16;
+    int band = 0;
+    for (int b = want; b <= tf; ++b)
+        if (tf % b == 0) { band = b; break; }
+    if (band == 0 || band == tf) return;
+    cg.band = band;
+    cg.tf = tf;
+}
+
+static int conv_launch(const void* x, const void* w, const void* bias, void* y, const fp_gemm::ConvGeom& cg_in, int Cout,
                        const void* resid, hipStream_t st) {
     using namespace fp_gemm;
+    ConvGeom cg = cg_in;
+    pick_band(cg);
     const int64_t M64 = (int64_t)cg.To * cg.Ho * cg.Wo;
     FP_REQUIRE(M64 < (1ll << 31) && (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin < (1ll << 40));
     // centre taps are packed t << 22 | h << 11 | w in gemm_w4.h, in tap coordinates (strided: twice the output's)
