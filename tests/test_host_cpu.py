@@ -258,12 +258,16 @@ def test_gemm_fragment_reads_all_feed_an_mfma(tmp_path):
     if not os.path.exists(hipcc):
         pytest.skip("needs hipcc")
     seen = 0
-    for fname in ("gemm_bf16.hip", "vae_kernels.hip"):
+    files = ("gemm_bf16.hip", "vae_kernels.hip")
+    procs = []                                # (the two compilations run side by side: about a minute each)
+    for fname in files:
         src = os.path.join(ROOT, "framepack_amd", "csrc", fname)
-        out = tmp_path / (fname + ".s")
-        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src, "-o", str(out)],
-                       check=True, capture_output=True)
-        text = out.read_text()
+        procs.append(subprocess.Popen([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", src,
+                                       "-o", str(tmp_path / (fname + ".s"))], stdout=subprocess.DEVNULL,
+                                      stderr=subprocess.DEVNULL))
+    for fname, pr in zip(files, procs):
+        assert pr.wait() == 0, fname
+        text = (tmp_path / (fname + ".s")).read_text()
         for m in re.finditer(r"^(_ZN7fp_gemm14gemm_w4_kernel\S*):[^\n]*\n(.*?)^\s*\.amdhsa_kernel \1", text, re.S | re.M):
             name, body = m.group(1), m.group(2)
             seen += 1
