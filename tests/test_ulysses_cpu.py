@@ -35,7 +35,17 @@ def _worker(rank, world, port, n_img_total, n_txt, heads, strided, chunks, ret):
         n, lo, valid = ulysses.row_shard(S, world, rank)
         pad = torch.full((n - valid, d), float("nan"))          # padding rows: whatever they hold must not matter
         lq0, lk0, lv0 = (torch.cat([t[lo:lo + valid], pad]) for t in (q, k, v))
-        if strided:                                   # q|k|v as column ranges of one buffer, output over q
+        if strided == "packed":                       # the send buffer already filled by the producer of q | k | v
+            hl = heads // world                       # (layout contract of ops.qk_rmsnorm_rope_pack / norm_kernels.hip)
+            hc = hl // chunks
+            pack = torch.empty(chunks, world, n, 3 * hc * 128)
+            for h in range(heads):
+                peer, chunk, hi = h // hl, (h % hl) // hc, h % hc
+                for which, t in enumerate((lq0, lk0, lv0)):
+                    pack[chunk, peer, :, which * hc * 128 + hi * 128:which * hc * 128 + (hi + 1) * 128] = t[:, h * 128:(h + 1) * 128]
+            raw = torch.full((n, d), float("nan"))    # q, k, v themselves are then only read for their shape
+            got = ulysses.ulysses_attention(raw, raw, raw, S, heads, 128, _attn, chunks=chunks, packed=pack)
+        elif strided:                                 # q|k|v as column ranges of one buffer, output over q
             buf = torch.cat([lq0, lk0, lv0, torch.zeros(n, 64)], dim=1)
             lq, lk, lv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
             got = ulysses.ulysses_attention(lq, lk, lv, S, heads, 128, _attn, out=lq, chunks=chunks)
@@ -59,7 +69,8 @@ def _free_port():
 @pytest.mark.parametrize("world,n_img,n_txt,heads,strided,chunks", [
     (2, 64, 9, 2, False, 1), (2, 50, 0, 4, True, 1), (4, 40, 7, 4, True, 1), (4, 41, 2, 4, False, 1),
     (2, 63, 10, 2, True, 1), (4, 2, 1, 4, False, 1),
-    (2, 63, 10, 4, True, 2), (2, 40, 7, 8, False, 2), (4, 41, 2, 8, True, 2)])      # two head chunks, overlapped exchanges
+    (2, 63, 10, 4, True, 2), (2, 40, 7, 8, False, 2), (4, 41, 2, 8, True, 2),       # two head chunks, overlapped exchanges
+    (2, 40, 7, 4, "packed", 1), (2, 63, 10, 8, "packed", 2), (4, 41, 2, 8, "packed", 2)])   # pre-filled send buffer
 def test_ulysses_attention_equals_unsharded(world, n_img, n_txt, heads, strided, chunks):
     ret = mp.get_context("spawn").Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), n_img, n_txt, heads, strided, chunks, ret), nprocs=world, join=True)
