@@ -203,6 +203,10 @@ def prep_w(w):          # [Cout, Cin, 3, 3, 3] -> [Cout, 27 * Cin] tap-major
     (2, 6, 6, 512, 512, (2, 2, 2), False),        # up block 0/1 upsampler
     (3, 10, 6, 512, 256, (1, 1, 1), False),       # up block 2, first resnet
     (2, 12, 12, 256, 128, (1, 1, 1), False),      # up block 3, first resnet (narrow tile)
+    # frames of 32 / 48 whole row tiles: the band-major walk of the output tiles (ConvGeom::band, vae_kernels.hip pick_band)
+    (3, 64, 128, 128, 128, (1, 1, 1), True),      # 32 tiles per frame -> bands of 16, narrow tiles
+    (2, 48, 128, 128, 256, (2, 2, 2), False),     # upsampled to 3 x 96 x 256 = 96 tiles per frame -> bands of 16, wide tiles
+    (4, 96, 128, 128, 32, (1, 1, 1), False),      # 48 tiles per frame, the conv_out tile (Cout <= 32)
 ])
 def test_conv3d_causal_at_real_widths(T, H, W, cin, cout, up, with_res):
     g = torch.Generator("cpu").manual_seed(1)
