@@ -338,6 +338,9 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
         self.sp_chunks = None          # head chunks per exchange (None: ulysses.pick_chunks decides)
         self._sp_total = 0
+        # single blocks under sequence parallelism: the MLP half of the in-projection runs while q | k | v are exchanged
+        # (_single_block); FRAMEPACK_SP_OVERLAP_MLP=0: one fused in-projection, exchange after it
+        self.sp_overlap_mlp = os.environ.get("FRAMEPACK_SP_OVERLAP_MLP", "1") != "0"
         self.fp8_compute = False       # block linears on the fp8 MFMA (enable_fp8_compute)
         # text stream of the double blocks on a low-priority side stream (_double_block); FRAMEPACK_TEXT_OVERLAP=0: off
         self.text_stream_overlap = os.environ.get("FRAMEPACK_TEXT_OVERLAP", "1") != "0"
@@ -443,7 +446,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.fp8_attention = bool(enable)
         return self
 
-    def _qk_attend(self, q, k, v, wq, wk, rope, n_img, wq_txt=None, wk_txt=None, normed=False):
+    def _qk_attend(self, q, k, v, wq, wk, rope, n_img, wq_txt=None, wk_txt=None, normed=False, overlap=None):
         """K2 (RMSNorm of q and k per head, RoPE on the image rows) and the joint attention over [image rows | text
         rows]; output written over q.  Under sequence parallelism K2 writes its results and v straight into the send
         buffer of the head exchange (q, k, v themselves stay raw: only the attention output lands in q)."""
@@ -460,7 +463,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                                               wq_txt=wq_txt, wk_txt=wk_txt)
             ulysses_attention(q, k, v, self._sp_total, self.heads, self.head_dim,
                               lambda jq, jk, jv, h, o: attn(jq, jk, jv, h, out=o), self.sp_group, out=q,
-                              chunks=chunks, packed=packed)
+                              chunks=chunks, packed=packed, overlap=overlap)
 
     @property
     def device(self):
@@ -754,6 +757,17 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         shift, scale, gate = mod.chunk(3)
+        if self.sp_world > 1 and self.sp_overlap_mlp and not isinstance(e.w_in, tuple):
+            # sequence parallel: the in-projection as two GEMMs over the same normalised rows - [k | v | q] first, the
+            # MLP half (57 % of the columns) while q | k | v are on their way to the owners of their heads.  Same
+            # arithmetic per output element as the one launch.
+            ops.layernorm_modulate(X, scale, shift, out=N)
+            ops.gemm(N, e.w_in[:3 * d], e.b_in[:3 * d], out=Y[:, :3 * d])
+            self._qk_attend(Y[:, 2 * d:3 * d], Y[:, :d], Y[:, d:2 * d], e.nq, e.nk, rope, Si,
+                            overlap=lambda: ops.gemm(N, e.w_in[3 * d:], e.b_in[3 * d:], out=Y[:, 3 * d:],
+                                                     epilogue=ops.EPI_GELU))
+            self._lin(ws, Y[:, 2 * d:], e.w_out, e.b_out, out=X, epilogue=ops.EPI_GATE_RESIDUAL, resid=X, gate=gate)
+            return
         normed = self._ln_lin_qk(ws, X, scale, shift, N, e.w_in, e.b_in, Y, e.nq, e.nk, rope, Si, 2 * d, 0,
                                  epilogue=ops.EPI_GELU_FROM, gelu_from=3 * d)               # [k | v | q | gelu(mlp)]
         k, v, q = Y[:, :d], Y[:, d:2 * d], Y[:, 2 * d:3 * d]

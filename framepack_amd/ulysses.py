@@ -61,7 +61,8 @@ def pick_chunks(n_total: int, heads_local: int, cus: int = 256) -> int:
 
 def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total: int, heads: int, head_dim: int,
                       attn_fn: Callable, group=None, out: Optional[torch.Tensor] = None,
-                      chunks: Optional[int] = None, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      chunks: Optional[int] = None, packed: Optional[torch.Tensor] = None,
+                      overlap: Optional[Callable[[], None]] = None) -> torch.Tensor:
     """q, k, v: [n, heads*head_dim] views (row-strided ok) holding this rank's run of the packed sequence (row_shard;
     padding rows included).  n_total = S, the valid rows over all ranks.  Returns / fills `out` (same shape; may be q)
     with the attention output of the local rows for all heads (padding rows: zeros).
@@ -70,7 +71,10 @@ def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total
     chunks: head chunks exchanged and attended one after the other so that communication overlaps attention
     (default: `pick_chunks`).
     packed: the send buffer [chunks, world, n, 3 * hc * head_dim] already filled by the producer of q | k | v
-    (ops.qk_rmsnorm_rope_pack: the RMSNorm/RoPE kernel writes it directly); q, k, v are then only read for their shape."""
+    (ops.qk_rmsnorm_rope_pack: the RMSNorm/RoPE kernel writes it directly); q, k, v are then only read for their shape.
+    overlap: work of the caller that needs nothing from the attention (the single blocks' MLP in-projection); it is
+    called once, after the forward exchanges have been issued - asynchronously then, whatever `chunks` - and before
+    the first of them is waited for, so its kernels run while q | k | v travel."""
     world = dist.get_world_size(group)
     if heads % world != 0:
         raise ValueError(f"{heads} heads do not divide over {world} ranks")
@@ -96,7 +100,10 @@ def ulysses_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_total
     else:
         send = torch.stack([t.reshape(n, world, chunks, hwc) for t in (q, k, v)], dim=3).permute(2, 1, 0, 3, 4).contiguous()
     joints = [torch.empty((world * n, 3 * hwc), dtype=dt, device=dev) for _ in range(chunks)]
-    fwd = [_all_to_all(joints[c], send[c].view(world * n, 3 * hwc), group, async_op=chunks > 1) for c in range(chunks)]
+    fwd = [_all_to_all(joints[c], send[c].view(world * n, 3 * hwc), group, async_op=chunks > 1 or overlap is not None)
+           for c in range(chunks)]
+    if overlap is not None:
+        overlap()
 
     # ---- per chunk: attention over the valid tokens of the local head chunk, written straight into the send buffer
     #      of the inverse exchange (rows past S: padding, zeros), which then runs under the next chunk's attention

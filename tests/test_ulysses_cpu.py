@@ -50,8 +50,10 @@ def _worker(rank, world, port, n_img_total, n_txt, heads, strided, chunks, ret):
             lq, lk, lv = buf[:, :d], buf[:, d:2 * d], buf[:, 2 * d:3 * d]
             got = ulysses.ulysses_attention(lq, lk, lv, S, heads, 128, _attn, out=lq, chunks=chunks)
         else:
+            calls = []                                # caller's work under the exchange: run once, exchange asynchronous
             got = ulysses.ulysses_attention(lq0.contiguous(), lk0.contiguous(), lv0.contiguous(), S, heads, 128, _attn,
-                                            chunks=chunks)
+                                            chunks=chunks, overlap=lambda: calls.append(1))
+            assert calls == [1]
         err = (got[:valid] - full[lo:lo + valid]).abs().max().item() if valid else 0.0
         gathered = ulysses.gather_rows(got.contiguous())[:S]
         err2 = (gathered - full).abs().max().item()

@@ -73,6 +73,12 @@ for P in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
         old_way = 60 * (timed(lambda: ops.qk_rmsnorm_rope_(ql, kl, wn, wn, rope, n, 24)) + timed(lambda: torch.stack(
             [x.reshape(n, P, ch, hwc) for x in (ql, kl, vl)], dim=3).permute(2, 1, 0, 3, 4).contiguous()))
         info = f" (K2 in place + a packing pass, replaced: {old_way:.1f})"
+        # the in-projection as two launches ([k | v | q], then the MLP half under the forward exchange: model._single_block)
+        qkv_ms = timed(lambda: ops.gemm(x3, W[21504][:9216], bias[21504][:9216], out=o21[:, :9216]))
+        mlp_ms = timed(lambda: ops.gemm(x3, W[21504][9216:], bias[21504][9216:], out=o21[:, 9216:], epilogue=1))
+        sent = n * 9216 * 2 * (P - 1) / P / 1e6
+        info += (f"; in-proj split x40: q|k|v {40 * qkv_ms:.1f} + mlp {40 * mlp_ms:.1f} (one launch: {t['in-proj x40']:.1f}); "
+                 f"the mlp launch ({mlp_ms * 1e3:.0f} us) covers the forward exchange of {sent:.1f} MB per rank")
     tot = sum(t.values())
     base = base or tot * P
     print(f"P={P} rows/rank {n} heads/rank {h}: " + " | ".join(f"{k} {v:.1f}" for k, v in t.items()) +
