@@ -20,8 +20,15 @@ for case in range(cases):
     g = torch.Generator().manual_seed(case)
     T, H, W = rnd.randint(1, 5), rnd.randint(1, 24), rnd.randint(1, 24)
     cin = rnd.choice([64, 64, 128, 128, 192, 256])
+    big = rnd.random() < 0.2          # frames of 32 - 64 whole row tiles: the band-major tile walk (pick_band, vae_kernels.hip)
+    if big:
+        T = rnd.randint(2, 4)
+        H, W = rnd.choice([(64, 128), (48, 192), (80, 128), (68, 128), (96, 96), (128, 128), (32, 256)])
+        cin = rnd.choice([128, 256])
     cout = 8 * rnd.choice([1, 4, 8, 9, 16, 17, 32])
     mode = rnd.choice(["plain", "plain", "up", "stride"])
+    if big and mode == "up":          # (the upsampled frame is the one that has to hold whole tiles)
+        H, W = H // 2, W // 2
     x = torch.randn(T, H, W, cin, generator=g).half()
     w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * (27 * cin) ** -0.5).half()
     b = (torch.randn(cout, generator=g) * 0.1).half()
