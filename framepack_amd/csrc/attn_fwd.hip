@@ -1080,16 +1080,17 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 }
 
 int cu_count() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
+    // (an atomic: the first calls may come from two threads at once - the reference runs forward() on a worker thread)
+    static std::atomic<int> n{0};
+    int v = n.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+            v = 256;
+        n.store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 }  // namespace

@@ -87,3 +87,23 @@ extern "C" int fp_gemm_bf16_qknorm(const void* a, int64_t lda, const void* w, in
     return launch_w4<bf16, 2, 0, bf16, 8, 1>(a, lda, a2_delta, k1, w, ldw, bias, c, ldc, M, N, K, gelu_from, nullptr, 0,
                                              nullptr, cg, st, nullptr, nullptr, qk);
 }
+
+// c [M, N] fp32 = a [M, K] . w [N, K]^T + bias (fp32 [N] or NULL), bf16 operands, fp32 accumulation written out unrounded.
+// The output head under `high_quality_fp32_output_for_inference` (ref hunyuan_video_packed.py:1048-1053: activations and
+// proj_out's weights upcast to fp32, then nn.Linear): both operands there are bf16 VALUES in fp32 containers, a product
+// of two bf16 values is exact in fp32, and the MFMA accumulates in fp32 - the same sum in another order.
+extern "C" int fp_gemm_bf16_f32out(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* c,
+                                   int64_t ldc, int M, int N, int K, void* stream) {
+    using namespace fp_gemm;
+    FP_REQUIRE(a && w && c && M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0);
+    FP_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0 && lda >= K && ldw >= K && ldc >= N);
+    FP_REQUIRE(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 15) == 0 && ((uintptr_t)bias & 15) == 0);
+    FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + 31) / 32) < (1ll << 31));
+    if (M == 0) return 0;
+    const ConvGeom cg{};
+    if (N <= 128)
+        return launch_w4<bf16, 0, 0, float, 4>(a, lda, 0, K, w, ldw, bias, c, ldc, M, N, K, 0, nullptr, 0, nullptr, cg,
+                                               (hipStream_t)stream);
+    return launch_w4<bf16, 0, 0, float>(a, lda, 0, K, w, ldw, bias, c, ldc, M, N, K, 0, nullptr, 0, nullptr, cg,
+                                        (hipStream_t)stream);
+}

@@ -467,11 +467,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     };
     auto epilogue = [&](int em0, int en0, int ecw) __attribute__((always_inline)) {
       if constexpr (sizeof(TO) == 4) {
-        // fp32 output (the VAE mid-block attention's logits; EPI 0, no bias): straight from the accumulators, 16 B per
-        // lane - a row tile's store covers 16 rows x 64 B per instruction.  N % 4 == 0.
+        // fp32 output (the VAE mid-block attention's logits, the DiT's fp32 head; EPI 0, optional fp32 bias): straight
+        // from the accumulators, 16 B per lane - a row tile's store covers 16 rows x 64 B per instruction.  N % 4 == 0.
         const int el = opaque_lane();
         const int fr = el & 15, fq = el >> 4;
         const int nb = en0 + wc * ecw + 4 * fq;
+        f32x4 bv[8];
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias && ni < NT) bv[ni] = *reinterpret_cast<const f32x4*>(bias + min(nb + ni * 16, N - 4));
+        }
         static_for<8>([&](auto MI_) __attribute__((always_inline)) {
             constexpr int mi = MI_;
             const int mrow0 = em0 + wr * 128 + mi * 16;
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                 constexpr int ni = NI_;
                 if constexpr (ni >= NT) return;
                 const int n = nb + ni * 16;
-                const f32x4 av = acc_read<(mi * 8 + ni) * 4>();
+                const f32x4 av = acc_read<(mi * 8 + ni) * 4>() + bv[ni];
                 if (mrow0 + fr < M && n < N) *reinterpret_cast<f32x4*>(C + (int64_t)(mrow0 + fr) * ldc + n) = av;
             });
         });

@@ -9,8 +9,11 @@
 //     replaces ref dit_common.py:9-10 + hunyuan_video_packed.py:453,476,502,642-643
 //     One wave per row; the row lives in registers between the statistics and the write, so the
 //     algorithmic traffic is one read + one write of the row.
+//     AFFINE: y = LayerNorm(x) * scale + shift - the token refiner's nn.LayerNorm(elementwise_affine=True) with
+//     scale = weight, shift = bias (ref hunyuan_video_packed.py:264, 273 through dit_common.py:9-10: F.layer_norm in the
+//     input dtype = fp32 arithmetic, one rounding).
 // ---------------------------------------------------------------------------------------------
-template <int NCH>   // NCH chunks of 512 elements per row (cols <= NCH*512)
+template <int NCH, bool AFFINE = false>   // NCH chunks of 512 elements per row (cols <= NCH*512)
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict__ x, int64_t x_rs,
                                                           const bf16* __restrict__ scale,
                                                           const bf16* __restrict__ shift,
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16* __restrict
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                o[j] = (bf16)((v[c][j] - mean) * rstd * (1.f + (float)sc[j]) + (float)sh[j]);
+                o[j] = (bf16)((v[c][j] - mean) * rstd * ((AFFINE ? 0.f : 1.f) + (float)sc[j]) + (float)sh[j]);
             *reinterpret_cast<bf16x8*>(yr + col) = o;
         }
     }
@@ -271,9 +274,9 @@ __global__ __launch_bounds__(64) void rel_l1_final_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-extern "C" int fp_layernorm_modulate_bf16(const void* x, int64_t x_row_stride, const void* scale, const void* shift,
-                                          void* y, int64_t y_row_stride, int rows, int cols, float eps,
-                                          void* stream) {
+template <bool AFFINE>
+static int ln_launch(const void* x, int64_t x_row_stride, const void* scale, const void* shift, void* y,
+                     int64_t y_row_stride, int rows, int cols, float eps, void* stream) {
     FP_REQUIRE(x && scale && shift && y && rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096);
     FP_REQUIRE(x_row_stride % 8 == 0 && y_row_stride % 8 == 0 && x_row_stride >= cols && y_row_stride >= cols);
     FP_REQUIRE(aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift));
@@ -283,13 +286,24 @@ extern "C" int fp_layernorm_modulate_bf16(const void* x, int64_t x_row_stride, c
     const bf16 *xp = (const bf16*)x, *sc = (const bf16*)scale, *sh = (const bf16*)shift;
     bf16* yp = (bf16*)y;
     if (cols <= 512)
-        ln_modulate_kernel<1><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, yp, y_row_stride, rows, cols, eps);
+        ln_modulate_kernel<1, AFFINE><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, yp, y_row_stride, rows, cols, eps);
     else if (cols <= 3072)
-        ln_modulate_kernel<6><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, yp, y_row_stride, rows, cols, eps);
+        ln_modulate_kernel<6, AFFINE><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, yp, y_row_stride, rows, cols, eps);
     else
-        ln_modulate_kernel<8><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, yp, y_row_stride, rows, cols, eps);
+        ln_modulate_kernel<8, AFFINE><<<grid, block, 0, st>>>(xp, x_row_stride, sc, sh, yp, y_row_stride, rows, cols, eps);
     FP_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fp_layernorm_modulate_bf16(const void* x, int64_t x_row_stride, const void* scale, const void* shift,
+                                          void* y, int64_t y_row_stride, int rows, int cols, float eps,
+                                          void* stream) {
+    return ln_launch<false>(x, x_row_stride, scale, shift, y, y_row_stride, rows, cols, eps, stream);
+}
+
+extern "C" int fp_layernorm_affine_bf16(const void* x, int64_t x_row_stride, const void* weight, const void* bias,
+                                        void* y, int64_t y_row_stride, int rows, int cols, float eps, void* stream) {
+    return ln_launch<true>(x, x_row_stride, weight, bias, y, y_row_stride, rows, cols, eps, stream);
 }
 
 extern "C" int fp_gate_residual_bf16(void* x, int64_t x_row_stride, const void* y, int64_t y_row_stride,

@@ -29,11 +29,13 @@ SIGNATURES = {
     "fp_qk_rmsnorm_rope_bf16": [P, P, L, I, I, I, P, P, P, P, P, I, F, P],
     "fp_qk_rmsnorm_rope_pack_bf16": [P, P, P, L, I, I, I, P, P, P, P, P, I, F, P, I, I, P],
     "fp_layernorm_modulate_bf16": [P, L, P, P, P, L, I, I, F, P],
+    "fp_layernorm_affine_bf16": [P, L, P, P, P, L, I, I, F, P],
     "fp_gate_residual_bf16": [P, L, P, L, P, I, I, P],
     "fp_silu_gemv_bf16": [P, P, P, P, I, I, I, P],
     "fp_rel_l1_acc_floats": [],
     "fp_rel_l1_bf16": [P, P, L, P, P],
     "fp_gemm_bf16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
+    "fp_gemm_bf16_f32out": [P, L, P, L, P, P, L, I, I, I, P],
     "fp_gemm_bf16_qknorm": [P, L, P, L, P, P, L, I, I, I, I, I, P, P, P, P, P, I, I, I, I, I, F, P],
     "fp_gemm_f16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_debug_gemm_variant": [I],

@@ -47,7 +47,10 @@ class _NormWeight(nn.Module):
 
 
 class _MLP2(nn.Module):
-    """linear_2(silu(linear_1(x))): TimestepEmbedding / PixArtAlphaTextProjection(act_fn='silu')."""
+    """linear_2(silu(linear_1(x))): TimestepEmbedding / PixArtAlphaTextProjection(act_fn='silu') (ref :191-231).  The
+    input is one vector per sample, so both linears are weight-streaming GEMVs: K7 (`fp_silu_gemv_bf16`), the first
+    without the SiLU, the second with it - the same rounding points as the reference's bf16 modules (linear_1's output
+    and the SiLU's are bf16)."""
 
     def __init__(self, d_in: int, d: int):
         super().__init__()
@@ -55,7 +58,12 @@ class _MLP2(nn.Module):
         self.linear_2 = nn.Linear(d, d)
 
     def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
+        l1, l2 = self.linear_1, self.linear_2
+        rows = []
+        for r in x.reshape(-1, x.shape[-1]):
+            h = ops.silu_gemv(r, l1.weight.detach(), l1.bias.detach(), apply_silu=False)
+            rows.append(ops.silu_gemv(h, l2.weight.detach(), l2.bias.detach(), apply_silu=True))
+        return torch.stack(rows).reshape(x.shape[:-1] + (l2.out_features,))
 
 
 class _ActProj(nn.Module):
@@ -184,7 +192,8 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
     run on K5 (`fp_gemm_bf16`, gated residuals in the epilogue), its masked attention on K1: under the reference's
     mask (outer AND of the key mask, column 0 forced visible, ref :337-340) a valid token attends to the valid tokens
     plus token 0, and a padding token to token 0 alone - i.e. K1 over those rows, and v[0] for the padding rows.
-    LayerNorm (affine), SiLU and the two vector MLPs stay torch ops on [512, d] / [1, d] tensors."""
+    The two affine LayerNorms per block are K3's affine form, the two vector MLPs and `norm_out.linear` K7 GEMVs; what
+    stays on torch are elementwise ops (the masked mean of the text states, the FF's SiLU)."""
 
     def __init__(self, in_channels, heads, head_dim, num_layers, mlp_ratio=4.0):
         super().__init__()
@@ -194,6 +203,14 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
         self.proj_in = nn.Linear(in_channels, d)
         self.token_refiner = _TokenRefinerStack(heads, head_dim, num_layers, mlp_ratio)
         self._packed = None            # fused q|k|v weights per block (rebuilt after .to() / load_state_dict)
+
+    def _apply(self, fn, *a, **k):                      # .to() / .cuda(): the fused copies go stale
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed = None
+        return super().load_state_dict(*a, **k)
 
     def _pack(self):
         with torch.inference_mode(False), torch.no_grad():
@@ -210,6 +227,10 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
     def forward(self, text, timestep, mask, info: Optional[_MaskInfo] = None):
         if not text.is_cuda:
             raise RuntimeError("HunyuanVideoTokenRefiner (MI355X build) runs on the GPU only; there is no CPU fallback")
+        with torch.cuda.device(text.device):
+            return self._forward(text, timestep, mask, info)
+
+    def _forward(self, text, timestep, mask, info):
         B, L, _ = text.shape
         assert B == 1, "the packed forward feeds the refiner one sample at a time"
         info = info or _MaskInfo(mask)
@@ -227,7 +248,7 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
         for blk, e in zip(self.token_refiner.refiner_blocks, P):
             gates = ops.silu_gemv(temb[0], blk.norm_out.linear.weight.detach(), blk.norm_out.linear.bias.detach())
             g_msa, g_mlp = gates[:d], gates[d:]
-            n1 = F.layer_norm(x, (d,), blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+            n1 = ops.layernorm_affine(x, blk.norm1.weight.detach(), blk.norm1.bias.detach(), blk.norm1.eps)
             qkv = ops.gemm(n1, e.w_qkv, e.b_qkv)                                                   # [L, q|k|v]
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             if mask is None:
@@ -244,7 +265,7 @@ class HunyuanVideoTokenRefiner(nn.Module):              # ref :348-394
                     att.index_copy_(0, info.invalid, v[0:1].expand(info.invalid.numel(), d))
             ops.gemm(att, blk.attn.to_out[0].weight.detach(), blk.attn.to_out[0].bias.detach(), out=x,
                      epilogue=ops.EPI_GATE_RESIDUAL, resid=x, gate=g_msa)
-            n2 = F.layer_norm(x, (d,), blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+            n2 = ops.layernorm_affine(x, blk.norm2.weight.detach(), blk.norm2.bias.detach(), blk.norm2.eps, out=n1)
             hdn = F.silu(ops.gemm(n2, blk.ff.net[0].proj.weight.detach(), blk.ff.net[0].proj.bias.detach()))
             ops.gemm(hdn, blk.ff.net[2].weight.detach(), blk.ff.net[2].bias.detach(), out=x,
                      epilogue=ops.EPI_GATE_RESIDUAL, resid=x, gate=g_mlp)
@@ -336,7 +357,9 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._ws = {}                  # grow-only activation backing store per device (see _workspace)
         self.taps = None               # optional dict: per-block outputs for parity tests
         self.sp_group, self.sp_world, self.sp_rank = None, 1, 0    # Ulysses sequence parallelism (off)
+        self.sp_on = False             # the sequence-parallel code path (a world of one rank can be made to take it)
         self.sp_chunks = None          # head chunks per exchange (None: ulysses.pick_chunks decides)
+        self._sp_bufs = {}             # the exchange's buffers, allocated once per shape (ulysses.exchange_buffers)
         self._sp_total = 0
         # single blocks under sequence parallelism: the MLP half of the in-projection runs while q | k | v are exchanged
         # (_single_block); FRAMEPACK_SP_OVERLAP_MLP=0: one fused in-projection, exchange after it
@@ -375,17 +398,21 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self.cache_misses = 0
         self.cache_queries = 0
 
-    def enable_sequence_parallel(self, group=None):
+    def enable_sequence_parallel(self, group=None, force: bool = False):
         """Shard the image tokens over the ranks of `group` (default: the world) and run the joint attention
         Ulysses-style (framepack_amd/ulysses.py).  Every rank calls forward() with the SAME inputs and gets
-        the SAME full output; weights are replicated.  No reference counterpart."""
+        the SAME full output; weights are replicated.  No reference counterpart.
+        A group of ONE rank keeps the single-GPU path unless `force` (the RCCL test on one GPU: every exchange,
+        gather and all-reduce of the sequence-parallel path then runs through the communicator, on one rank)."""
         import torch.distributed as dist
         self.sp_group = group
         self.sp_world = dist.get_world_size(group)
         self.sp_rank = dist.get_rank(group)
         if self.heads % self.sp_world != 0:
             raise ValueError(f"{self.heads} heads do not divide over {self.sp_world} ranks")
+        self.sp_on = self.sp_world > 1 or force
         self._ws = {}
+        self._sp_bufs = {}
 
     def _cached(self, slot: str, src: torch.Tensor, fn):
         """Cross-step cache of work that depends only on a tensor the caller passes unchanged for every step of a
@@ -451,7 +478,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         rows]; output written over q.  Under sequence parallelism K2 writes its results and v straight into the send
         buffer of the head exchange (q, k, v themselves stay raw: only the attention output lands in q)."""
         attn = ops.attention_fp8 if self.fp8_attention else ops.attention
-        if self.sp_world == 1:
+        if not self.sp_on:
             if not normed:                      # (normed: K2 was applied in the producing GEMM's epilogue, _ln_lin_qk)
                 ops.qk_rmsnorm_rope_(q, k, wq, wk, rope, n_img, self.heads, wq_txt=wq_txt, wk_txt=wk_txt)
             attn(q, k, v, self.heads, out=q)
@@ -459,11 +486,14 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             from .ulysses import pick_chunks, ulysses_attention
             hl = self.heads // self.sp_world
             chunks = self.sp_chunks if self.sp_chunks is not None else pick_chunks(self._sp_total, hl)
+            from .ulysses import exchange_buffers
+            hwc = hl // chunks * self.head_dim
+            send = exchange_buffers(self._sp_bufs, chunks, self.sp_world, q.shape[0], hwc, q.dtype, q.device)["send"]
             packed = ops.qk_rmsnorm_rope_pack(q, k, v, wq, wk, rope, n_img, self.heads, self.sp_world, chunks,
-                                              wq_txt=wq_txt, wk_txt=wk_txt)
+                                              wq_txt=wq_txt, wk_txt=wk_txt, out=send)
             ulysses_attention(q, k, v, self._sp_total, self.heads, self.head_dim,
                               lambda jq, jk, jv, h, o: attn(jq, jk, jv, h, out=o), self.sp_group, out=q,
-                              chunks=chunks, packed=packed, overlap=overlap)
+                              chunks=chunks, packed=packed, overlap=overlap, bufs=self._sp_bufs)
 
     @property
     def device(self):
@@ -683,7 +713,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
     def _fuse_qk(self, w, out) -> bool:
         """K2 in the q | k | v GEMM's epilogue (ops.gemm_qknorm): one GPU, bf16 weights, output aligned for the 4-wave
         kernel; off by default (`fuse_qk_norm`, FRAMEPACK_FUSE_QK=1: see __init__)."""
-        return (self.fuse_qk_norm and self.sp_world == 1 and not isinstance(w, tuple) and w.dtype == torch.bfloat16
+        return (self.fuse_qk_norm and not self.sp_on and not isinstance(w, tuple) and w.dtype == torch.bfloat16
                 and ops.gemm_qknorm_ok(out))
 
     def _ln_lin_qk(self, ws, x, sc, sh, n, w, b, out, wq, wk, rope, rope_rows, qcol0, kcol0, **kw):
@@ -757,7 +787,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         d, H = self.inner_dim, self.heads
         X, N, Y = ws.X, ws.N, ws.Y
         shift, scale, gate = mod.chunk(3)
-        if self.sp_world > 1 and self.sp_overlap_mlp and not isinstance(e.w_in, tuple):
+        if self.sp_on and self.sp_overlap_mlp and not isinstance(e.w_in, tuple):
             # sequence parallel: the in-projection as two GEMMs over the same normalised rows - [k | v | q] first, the
             # MLP half (57 % of the columns) while q | k | v are on their way to the owners of their heads.  Same
             # arithmetic per output element as the one launch.
@@ -778,7 +808,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         """(low-priority stream, two events) for the text stream of the double blocks, per device; None where the
         overlap is off: fp8 compute (one shared quantiser scratch), sequence parallelism (rows are not split by stream
         there), block taps (they read X between blocks), `text_stream_overlap = False`."""
-        if not self.text_stream_overlap or self.sp_world != 1 or self.taps is not None or self.fp8_compute:
+        if not self.text_stream_overlap or self.sp_on or self.taps is not None or self.fp8_compute:
             return None
         key = device.index
         if key not in self._side_streams:
@@ -838,7 +868,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
 
             def cut(x, b):
                 return None if x is None else x[b:b + 1]
-            with torch.no_grad():
+            with torch.no_grad(), torch.cuda.device(hidden_states.device):
                 outs = [self._forward(*(cut(x, b) for x in (
                     hidden_states, timestep, encoder_hidden_states, encoder_attention_mask, pooled_projections,
                     guidance, latent_indices, clean_latents, clean_latent_indices, clean_latents_2x,
@@ -846,7 +876,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                     for b in range(batch_size)]
             out = torch.cat(outs, dim=0)
             return Transformer2DModelOutput(sample=out) if return_dict else (out,)
-        with torch.no_grad():
+        # (the kernels launch on the CURRENT device: a model on cuda:1 works without the caller's set_device)
+        with torch.no_grad(), torch.cuda.device(hidden_states.device):
             return self._forward(hidden_states, timestep, encoder_hidden_states, encoder_attention_mask,
                                  pooled_projections, guidance, latent_indices, clean_latents, clean_latent_indices,
                                  clean_latents_2x, clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices,
@@ -871,7 +902,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         if encoder_attention_mask is None:
             minfo = _MaskInfo(None)
         else:
-            minfo = self._cached("mask_info", encoder_attention_mask, lambda: _MaskInfo(encoder_attention_mask.to(dev)))
+            # (one entry per mask tensor: with a negative prompt two masks alternate every step)
+            slot = f"mask_info@{encoder_attention_mask.data_ptr():x}"
+            if slot not in self._invariant:
+                for old in [k_ for k_ in self._invariant if k_.startswith("mask_info@")][3:]:
+                    del self._invariant[old]
+            minfo = self._cached(slot, encoder_attention_mask, lambda: _MaskInfo(encoder_attention_mask.to(dev)))
             encoder_attention_mask = encoder_attention_mask.to(dev)
         ctx = self.context_embedder(encoder_hidden_states, timestep, encoder_attention_mask, minfo)
         text_len = ctx.shape[1] if minfo.n_valid is None else minfo.n_valid
@@ -888,7 +924,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         # packed image tokens straight into the residual-stream buffer
         n_img = self._count_image_tokens(hidden_states, clean_latents, clean_latent_indices, clean_latents_2x,
                                          clean_latent_2x_indices, clean_latents_4x, clean_latent_4x_indices)
-        if self.sp_world == 1:
+        if not self.sp_on:
             lo, Si = 0, n_img
             S = Si + text_len
             ws = self._workspace(S, dev)
@@ -936,7 +972,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
                 self.cache_misses += 1
             else:
                 acc_t = ops.rel_l1(modulated, self.previous_modulated_input, ws.acc) if Si > 0 else ws.acc[:2].zero_()
-                if self.sp_world > 1:                       # identical decision on every rank
+                if self.sp_on:                              # identical decision on every rank
                     import torch.distributed as dist
                     dist.all_reduce(acc_t, group=self.sp_group)
                 acc = acc_t.tolist()                                           # host sync (ref :958)
@@ -968,7 +1004,7 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
 
         # output head (ref :1044-1057): norm_out is token-wise, so slice first; (scale, shift) order of :501
         scale, shift = mods[-2 * d:-d], mods[-d:]
-        if self.sp_world == 1:
+        if not self.sp_on:
             # the noisy-latent tokens are the last ctx_len rows of the image sequence
             first = n_img - ctx_len
             head_in = ops.layernorm_modulate(ws.X[first:Si], scale, shift, out=ws.N[:Si - first])
@@ -976,13 +1012,25 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             # every rank runs the (tiny) head over all of its rows; the noisy-latent rows are cut out of the gather
             head_in = ops.layernorm_modulate(ws.X, scale, shift, out=ws.N)
         if self.high_quality_fp32_output_for_inference:
+            # ref :1048-1053: activations and proj_out's weights upcast to fp32 (in place, at the first call), then the
+            # Linear.  The operands are then bf16 VALUES in fp32 containers, whose products are exact in fp32: K5 with the
+            # accumulators written out in fp32 computes the same sum.  Only a proj_out that was loaded with genuine fp32
+            # weights (never the product's bf16 checkpoint) cannot go that way and takes torch's fp32 Linear.
             if self.proj_out.weight.dtype != torch.float32:
                 self.proj_out.to(dtype=torch.float32)
                 self._packed = P          # proj_out is not part of the fused buffers
-            out = F.linear(head_in.float(), self.proj_out.weight, self.proj_out.bias)
+            head = getattr(P, "head32", None)
+            if head is None or head[0] is not self.proj_out.weight:
+                w32 = self.proj_out.weight.detach()
+                w16 = w32.to(BF16)
+                head = P.head32 = (self.proj_out.weight, w16.contiguous(), bool((w16.float() == w32).all()))
+            if head[2]:
+                out = ops.gemm_f32out(head_in, head[1], self.proj_out.bias.detach().float().contiguous())
+            else:
+                out = F.linear(head_in.float(), self.proj_out.weight, self.proj_out.bias)
         else:
             out = ops.gemm(head_in, self.proj_out.weight.detach(), self.proj_out.bias.detach())
-        if self.sp_world > 1:
+        if self.sp_on:
             from .ulysses import gather_rows
             out = gather_rows(out, self.sp_group)[n_img - ctx_len:n_img]
         if self.taps is not None:

@@ -73,6 +73,26 @@ def layernorm_modulate(x: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor
     return out
 
 
+def layernorm_affine(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-6,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K3, affine form: LN(x) * weight + bias (the token refiner's nn.LayerNorm).  x [rows, cols], weight/bias [cols]."""
+    _dev(x, weight, bias, out)
+    x2, rows, cols, xs = _rows2d(x)
+    if out is None:
+        out = torch.empty((rows, cols), dtype=BF16, device=x.device)
+    o2, orows, ocols, os_ = _rows2d(out)
+    assert x.dtype == BF16 and out.dtype == BF16 and (orows, ocols) == (rows, cols)
+    weight = weight.reshape(-1).contiguous()
+    bias = bias.reshape(-1).contiguous()
+    assert weight.numel() == cols and bias.numel() == cols and weight.dtype == BF16 and bias.dtype == BF16
+    if rows == 0:
+        return out
+    _lib.check(_lib.load().fp_layernorm_affine_bf16(x2.data_ptr(), xs, weight.data_ptr(), bias.data_ptr(),
+                                                    o2.data_ptr(), os_, rows, cols, eps, _stream(x)),
+               "fp_layernorm_affine_bf16")
+    return out
+
+
 def gate_residual_(x: torch.Tensor, y: torch.Tensor, gate: torch.Tensor) -> torch.Tensor:
     """K4: x += gate * y in place."""
     _dev(x, y, gate)
@@ -309,6 +329,26 @@ def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
     _lib.check(fn(a_.data_ptr(), lda, None if a2 is None else a2_.data_ptr(), k1, w_.data_ptr(), ldw,
                                         _ptr(bias), o_.data_ptr(), ldc, M, N, K, epilogue, gelu_from, rptr, ldr, gptr,
                _stream(a)), "fp_gemm_bf16" if dt == BF16 else "fp_gemm_f16")
+    return out
+
+
+def gemm_f32out(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K5 with fp32 output: out [M,N] fp32 = a [M,K] @ weight [N,K].T + bias, a / weight bf16, bias fp32 [N] or None
+    (the fp32 head of `high_quality_fp32_output_for_inference`)."""
+    _dev(a, weight, bias, out)
+    a_, M, K, lda = _rows2d(a)
+    w_, N, Kw, ldw = _rows2d(weight)
+    assert K == Kw and a.dtype == BF16 and weight.dtype == BF16
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous())
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    o_, Mo, No, ldc = _rows2d(out)
+    assert (Mo, No) == (M, N) and out.dtype == torch.float32
+    if M == 0:
+        return out
+    _lib.check(_lib.load().fp_gemm_bf16_f32out(a_.data_ptr(), lda, w_.data_ptr(), ldw, _ptr(bias), o_.data_ptr(), ldc,
+                                               M, N, K, _stream(a)), "fp_gemm_bf16_f32out")
     return out
 
 

@@ -576,6 +576,10 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         decoded by rank n % P and broadcast; every rank then does the same cross-fade.  Results are identical to
         the single-GPU framewise decode."""
         import torch.distributed as dist
+        if getattr(self, "_tp_group", None) is not None:
+            # (a window's owner would wait in its tile's halo exchange for ranks that wait in the window's broadcast)
+            raise RuntimeError("enable_window_parallel and enable_tile_parallel exclude each other: a decode is split "
+                               "either by windows or by bands of rows")
         self._wp_group = group if group is not None else dist.group.WORLD
 
     def enable_tile_parallel(self, group=None) -> None:
@@ -586,6 +590,9 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         33-frame section) every rank works on every window, and the result equals the single-GPU decode up to the
         rounding of the GroupNorm moments.  Every rank calls decode() with the same latents and gets the same frames."""
         import torch.distributed as dist
+        if getattr(self, "_wp_group", None) is not None:
+            raise RuntimeError("enable_window_parallel and enable_tile_parallel exclude each other: a decode is split "
+                               "either by windows or by bands of rows")
         self._tp_group = group if group is not None else dist.group.WORLD
 
     def _framewise(self, z: torch.Tensor, tile_fn) -> torch.Tensor:

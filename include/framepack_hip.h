@@ -101,6 +101,13 @@ int fp_qk_rmsnorm_rope_pack_bf16(const void* q, const void* k, const void* v, in
 int fp_layernorm_modulate_bf16(const void* x, int64_t x_row_stride, const void* scale, const void* shift,
                                void* y, int64_t y_row_stride, int rows, int cols, float eps, void* stream);
 
+/* K3, affine form: y = LayerNorm(x; eps) * weight + bias,  weight, bias: [cols] - the token refiner's two
+ * nn.LayerNorm(elementwise_affine=True) per block (hunyuan_video_packed.py:264, 273, run through
+ * dit_common.py:9-10 LayerNorm_forward: F.layer_norm in the input dtype, i.e. fp32 arithmetic and one rounding).
+ * Same kernel, limits and layout as fp_layernorm_modulate_bf16. */
+int fp_layernorm_affine_bf16(const void* x, int64_t x_row_stride, const void* weight, const void* bias,
+                             void* y, int64_t y_row_stride, int rows, int cols, float eps, void* stream);
+
 /* K4  x += gate * y,  x,y: [rows, cols], gate: [cols].
  * Replaces hunyuan_video_packed.py:636-637, 649-650, 570-571. */
 int fp_gate_residual_bf16(void* x, int64_t x_row_stride, const void* y, int64_t y_row_stride,
@@ -131,6 +138,15 @@ int fp_rel_l1_bf16(const void* a, const void* b, int64_t n, float* acc, void* st
 int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void* w, int64_t ldw,
                  const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
                  const void* resid, int64_t ldr, const void* gate, void* stream);
+
+/* K5 with the accumulators written out in fp32: c [M, N] fp32 = a [M, K] . w [N, K]^T + bias, a and w bf16, bias fp32
+ * [N] or NULL.  The output head under `high_quality_fp32_output_for_inference` (hunyuan_video_packed.py:1048-1053:
+ * activations and proj_out's weights upcast to fp32, then nn.Linear; framepack/models.py:241 always sets the flag): both
+ * operands there are bf16 values in fp32 containers, whose products are exact in fp32, so the bf16 MFMA with fp32
+ * accumulation computes the same sum (in another order).  K % 64 == 0, N % 8 == 0, ldc % 4 == 0, c and bias 16-byte
+ * aligned. */
+int fp_gemm_bf16_f32out(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, void* c,
+                        int64_t ldc, int M, int N, int K, void* stream);
 
 /* K5 + K2 in one launch: the q | k | v projection of a double-stream block (hunyuan_video_packed.py:552-563,
  * epilogue 0) or the fused in-projection of a single-stream block (:570-579, epilogue 2: tanh-GELU on columns >=

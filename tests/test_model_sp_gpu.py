@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, case, teacache, fp8_attention, heads, chunks, ret):
+def _worker(rank, world, port, case, teacache, fp8_attention, heads, chunks, ret, wide=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,9 +26,15 @@ def _worker(rank, world, port, case, teacache, fp8_attention, heads, chunks, ret
         from framepack_amd import synthetic
         from framepack_amd.model import HunyuanVideoTransformer3DModelPacked
         bf, dev = torch.bfloat16, "cuda:0"
-        m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_TINY, num_attention_heads=heads)).to(bf)
+        if wide:        # 13B width (24 heads x 128, mlp 12 288), one double + one single block
+            m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_13B, num_layers=1, num_single_layers=1)).to(bf)
+        else:
+            m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_TINY, num_attention_heads=heads)).to(bf)
         synthetic.init_synthetic_(dict(m.state_dict()), seed=0)
         m = m.to(dev).eval()
+        if wide:
+            from framepack_amd.ulysses import pick_chunks
+            assert m.heads // world == 12 and pick_chunks(19385, 12) == 2      # the overlapped two-chunk exchange
         if fp8_attention:
             m.enable_fp8_attention()       # per-head scales over all rows: the same on one GPU and on a head group
         kw = synthetic.make_inputs(dtype=bf, **case)
@@ -62,6 +68,8 @@ def _worker(rank, world, port, case, teacache, fp8_attention, heads, chunks, ret
 CASES = {
     "config1": dict(seed=31337, frames_latent=3, height=256, width=256, n_text=37, sigma=0.9375),
     "odd_text": dict(seed=8, frames_latent=2, height=96, width=160, n_text=1, sigma=0.05),
+    # BASELINE config 3's shape: the 640 x 640 x 33-frame section with 256 text tokens, S = 19 385
+    "config3": dict(seed=31337, frames_latent=9, height=640, width=640, n_text=256, sigma=0.7),
 }
 
 
@@ -78,5 +86,19 @@ def test_sequence_parallel_forward_equals_single_gpu(case, teacache, fp8_attenti
     for err, same_counts, split_is_bit_identical in ret.values():
         # same kernels on the same values; only the order of the keys inside the attention (and the tile split of
         # the GEMMs) differs between the two runs
+        assert err < 4e-3 and same_counts
+        assert split_is_bit_identical
+
+
+def test_sequence_parallel_forward_at_13b_width_and_product_length():
+    """BASELINE config 3 as far as one GPU goes: 13B-width blocks (1 double + 1 single) at S = 19 385, two ranks (12 heads
+    each: `pick_chunks` = 2, the single block's in-projection split around the exchange) against the same model's
+    single-GPU forward.  The scaling curve itself is unmeasured here (one GPU)."""
+    world = 2
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), CASES["config3"], False, False, 24, None, ret, True), nprocs=world,
+             join=True)
+    assert len(ret) == world
+    for err, same_counts, split_is_bit_identical in ret.values():
         assert err < 4e-3 and same_counts
         assert split_is_bit_identical
