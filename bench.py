@@ -147,6 +147,7 @@ def main():
         model = HunyuanVideoTransformer3DModelPacked(**cfg_kw).to(bf)
     synthetic.init_synthetic_(dict(model.state_dict()), seed=0, fast_device_rng=True)
     model.eval()
+    model.high_quality_fp32_output_for_inference = True        # the product's setting (ref framepack/models.py:241)
     if args.fp8:
         model.enable_fp8_compute()
         model.enable_fp8_attention()

@@ -16,8 +16,12 @@
 //     V image: [d/32][key][64 B]                                      -> conflict-free tr reads.
 //   * Tails: rows are clamped on load, scores of keys past the segment end are masked to -inf in the
 //     last tile only, query rows past the end are not stored.  Nothing is padded in memory.
-//   * The items of the last, partial round of workgroups are cut into KV ranges (fp32 partials in a workspace) and
-//     merged by attn_combine_kernel.
+//   * The last items of a launch are cut into KV ranges ("parts": fp32 partials in a workspace, merged by
+//     attn_combine_kernel), and the parts are not bound to blocks: a part block takes the next part from a counter in the
+//     workspace.  The hardware deals blocks to the 8 XCDs round-robin and the dies do not run at one speed (per-workgroup
+//     timeline, tools/attn_timeline.py: the same sweep takes 446 us on one XCD and 481 us on another of the same chip), so
+//     with one part per block the launch ended when the slowest die had done its share and the fastest had idled for 6 %
+//     of the launch; now the dies that finish their whole sweeps first take most of the parts.
 // attn_w64_kernel (second generation, variant 1) and attn_v3_kernel (third, default) are described at their definitions.
 #include <atomic>
 #include <mutex>
@@ -30,6 +34,8 @@ constexpr int KVBLK = 64;     // keys per tile
 constexpr int HD = 128;       // head dim
 constexpr int KBUF = KVBLK * HD * 2;   // 16 KiB per K (or V) buffer
 constexpr int WS_FLOATS = 256 * HD + 2 * 256;   // one partial sweep: O[256][128], m[256], l[256] (fp32)
+constexpr int WS_HEAD_BYTES = 256;              // the workspace starts with the part counter (int), then the partials
+constexpr int PART_BLOCKS_PER_PART = 3;
 
 __device__ __forceinline__ unsigned k_lds_off(int key, int chunk) {      // chunk = 16-B piece of the 256-B row
     return (unsigned)(key * 256 + ((chunk ^ (key & 15)) << 4));
@@ -135,13 +141,44 @@ constexpr int w64_dma_of_slot(int m) {
     return k < 8 ? k : -1;
 }
 
+
+// Work of this block.  Blocks [0, nwg_full): one whole sweep each, XCD-contiguous.  Blocks beyond: "part blocks" - each
+// takes the next part (item, KV range) from the counter at the start of the workspace, or leaves if none is left (more
+// part blocks are launched than there are parts, so that a die that is ahead can take more than its round-robin share).
+// Returns false if the block has nothing to do.  `smem` is used for the hand-over (before the rings are).
+__device__ __forceinline__ bool pick_work(int& w, int& part, int& nparts, int nwg_full, int split, int n_parts_total,
+                                          int* __restrict__ part_counter, unsigned char* smem) {
+    part = 0;
+    nparts = 1;
+    if ((int)blockIdx.x < nwg_full) {
+        w = xcd_remap(blockIdx.x, nwg_full);
+        return true;
+    }
+    int p;
+    if (part_counter) {
+        if (threadIdx.x == 0)
+            *reinterpret_cast<volatile int*>(smem) = __hip_atomic_fetch_add(part_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        p = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+        __syncthreads();                        // (every wave has read it before any wave's LDS-DMA lands there)
+    } else {
+        p = blockIdx.x - nwg_full;              // (static: the fp8 variant's launcher and callers without a counter)
+    }
+    if (p >= n_parts_total) return false;
+    w = nwg_full + p / split;
+    part = p % split;
+    nparts = split;
+    return true;
+}
+
 template <int THR_LOG2>
 __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict__ Q, const bf16* __restrict__ K,
                                                           const bf16* __restrict__ V, bf16* __restrict__ O,
                                                           int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
                                                           const int* __restrict__ cu_seqlens, int nseg, int total,
                                                           int heads, int nqb, float scale_log2e, int nwg_full,
-                                                          int split, float* __restrict__ ws) {
+                                                          int split, float* __restrict__ ws, int n_parts_total,
+                                                          int* __restrict__ part_counter) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // K ring [3][16 KiB] | V ring [3][16 KiB]
     constexpr int VRING = 3 * KBUF;
     constexpr int QBLK = 256;
@@ -150,15 +187,8 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
     const int r = lane & 31, hh = lane >> 5;
     asm volatile("" ::: "a0", "a255");          // the kernel descriptor must count the AGPRs the asm below names
 
-    int w, part = 0, nparts = 1;
-    if ((int)blockIdx.x < nwg_full) {
-        w = xcd_remap(blockIdx.x, nwg_full);
-    } else {
-        const int si = blockIdx.x - nwg_full;
-        w = nwg_full + si / split;
-        part = si % split;
-        nparts = split;
-    }
+    int w, part, nparts;
+    if (!pick_work(w, part, nparts, nwg_full, split, n_parts_total, part_counter, smem)) return;
     const int qb = w % nqb;
     const int head = (w / nqb) % heads;
     const int seg = w / (nqb * heads);
@@ -512,8 +542,9 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
 //                                even slots    one fragment read (f + 3 while f is multiplied)
 // Timing-only builds (tools/attn_skip_probe.sh): -DFP_V3_SKIP=<mask> leaves one stream of the tile loop out (results are
 // then wrong): 1 exp2/pack/sum items, 2 LDS fragment reads, 4 LDS-DMA issues, 8 the per-tile barrier, 16 P.V MFMAs,
-// 32 Q.K MFMAs, 128 never take the slow path after the first tile (for builds whose scores are garbage).  The shipped
-// library is built without it.
+// 32 Q.K MFMAs, 128 never take the slow path after the first tile (for builds whose scores are garbage), 256 every V^T
+// fragment by ONE ds_read_b128 (what a V delivered pre-transposed would cost), 512 the barrier in every other tile only
+// (what 128-key iterations would save of it).  The shipped library is built without it.
 #ifndef FP_V3_SKIP
 #define FP_V3_SKIP 0
 #endif
@@ -523,6 +554,17 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
 // across the loop (this kernel has none to spare).
 #ifdef FP_V3_DIAG
 __device__ unsigned long long fp_attn_dbg[8];
+// -DFP_V3_DIAG=3: per-workgroup timeline (100 MHz real-time stamps): entry, tile loop start, tile loop end, after the
+// output stores have completed; and where it ran (HW_ID | XCC_ID << 32).  Read with fp_attn_tl_read.
+constexpr int FP_TL_MAX = 4096;
+__device__ unsigned long long fp_attn_tl[FP_TL_MAX * 5];
+#define FP_TL_STAMP(slot)                                                                                    \
+    do {                                                                                                      \
+        if (FP_V3_DIAG >= 3 && tid == 0 && blockIdx.x < FP_TL_MAX)                                            \
+            fp_attn_tl[blockIdx.x * 5 + (slot)] = __builtin_amdgcn_s_memrealtime();                          \
+    } while (0)
+#else
+#define FP_TL_STAMP(slot) do {} while (0)
 #endif
 // s = A . Q'[QIDX] + c   (first MFMA of a chain; D and C are different VGPR blocks)
 template <int QIDX, int LGKM> __device__ __forceinline__ void mfma_s_first(f32x16& s, const bf16x8& a, const f32x16& c) {
@@ -553,7 +595,7 @@ constexpr int v3_dma_of_slot(int m) {
 }
 // LDS read instructions still in flight behind fragment f when its first MFMA issues: fragments f+1 and f+2
 // (V^T fragments 0..15 take two reads, K fragments 16..31 one, 32..34 are the next tile's first V^T fragments)
-constexpr int v3_reads_of(int f) { return f < 16 ? 2 : (f < 32 ? 1 : 2); }
+constexpr int v3_reads_of(int f) { return (FP_V3_SKIP & 256) ? 1 : (f < 16 ? 2 : (f < 32 ? 1 : 2)); }
 constexpr int v3_lgkm(int f) { return v3_reads_of(f + 1) + v3_reads_of(f + 2); }
 // One wait per TWO fragments: the first MFMA of an even fragment f waits for f and f + 1 (requested four MFMAs ago),
 // leaving only f + 2 in flight; the odd fragment's MFMAs then need no wait
@@ -565,25 +607,30 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
                                                          int64_t q_rs, int64_t k_rs, int64_t v_rs, int64_t o_rs,
                                                          const int* __restrict__ cu_seqlens, int nseg, int total,
                                                          int heads, int nqb, float scale_log2e, int nwg_full,
-                                                         int split, float* __restrict__ ws) {
+                                                         int split, float* __restrict__ ws, int n_parts_total,
+                                                         int* __restrict__ part_counter) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // K ring [3][16 KiB] | V ring [4][16 KiB]
     constexpr int VRING = 3 * KBUF;
     constexpr int QBLK = 256;
     constexpr int QA = 128;                     // Q' fragments: a[QA + (rb * 8 + ks) * 4 ..]
     const float rs_limit = __builtin_ldexpf(1.f, THR_LOG2);               // a tile's row sums stay below 2^THR
     const int tid = threadIdx.x, lane = tid & 63;
+    FP_TL_STAMP(0);
+#if defined(FP_V3_DIAG) && FP_V3_DIAG >= 3
+    if (tid == 0 && blockIdx.x < FP_TL_MAX)
+        fp_attn_tl[blockIdx.x * 5 + 4] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+                                         ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     asm volatile("" ::: "a0", "a255");          // the kernel descriptor must count the AGPRs the asm below names
 
-    int w, part = 0, nparts = 1;
-    if ((int)blockIdx.x < nwg_full) {
-        w = xcd_remap(blockIdx.x, nwg_full);
-    } else {
-        const int si = blockIdx.x - nwg_full;
-        w = nwg_full + si / split;
-        part = si % split;
-        nparts = split;
+    int w, part, nparts;
+    if (!pick_work(w, part, nparts, nwg_full, split, n_parts_total, part_counter, smem)) {
+#if defined(FP_V3_DIAG) && FP_V3_DIAG >= 3
+        if (tid == 0 && blockIdx.x < FP_TL_MAX) fp_attn_tl[blockIdx.x * 5 + 3] = 0;      // (no work: not on the timeline)
+#endif
+        return;
     }
     const int qb = w % nqb;
     const int head = (w / nqb) % heads;
@@ -726,6 +773,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             u32x2 h[2];
             bf16x8 v;
         } a;
+        if constexpr (FP_V3_SKIP & 256) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4) * 64));
+            return;
+        }
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[0]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4) * 64));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[1]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4 + 8) * 64));
         f = a.v;
@@ -774,7 +825,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
     auto step = [&](int t, auto PAR, auto INNER) __attribute__((always_inline)) {
         constexpr int CUR = PAR, NXT = 1 - PAR;
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");              // all but this wave's last 8 pieces: K(t+1), V(t) are in
-        if constexpr (!(FP_V3_SKIP & 8)) __builtin_amdgcn_s_barrier();
+        if constexpr (!(FP_V3_SKIP & 8) && !((FP_V3_SKIP & 512) && PAR == 1)) __builtin_amdgcn_s_barrier();
         fence();
         unsigned kbase = (unsigned)kslot_rd + k_lane_base;
         const unsigned vbase = (unsigned)vslot_rd + v_lane_off;
@@ -954,6 +1005,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         fp_attn_dbg[3] = 0;
     }
 #endif
+    FP_TL_STAMP(1);
     {
         // step t loads K(t+3) and V(t+2) (tiles counted from t0): all of their rows are the segment's own while
         // t0 + t + 3 < nkv / 64.  Those steps run without the per-row clamp; the last few (and a short segment) with it.
@@ -976,6 +1028,7 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         fp_attn_dbg[2] = (unsigned long long)nt;
     }
 #endif
+    FP_TL_STAMP(2);
     // ---- the last tile's P.V (its V tile landed before the last barrier; the prefetched fragments are read again)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("" ::"v"(fr[0]), "v"(fr[1]), "v"(fr[2]));    // registers of the in-flight prefetch stay allocated until here
@@ -1017,6 +1070,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
                 wsp[256 * HD + 256 + row] = l_tot[rb];
             }
         });
+#if defined(FP_V3_DIAG) && FP_V3_DIAG >= 3
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FP_TL_STAMP(3);
+#endif
         return;
     }
     static_for<2>([&](auto rb) __attribute__((always_inline)) {
@@ -1035,6 +1092,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             });
         }
     });
+#if defined(FP_V3_DIAG) && FP_V3_DIAG >= 3
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FP_TL_STAMP(3);
+#endif
 }
 
 // Merge the `split` partial sweeps of each tail item: O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M).
@@ -1097,7 +1158,7 @@ int cu_count() {
 
 // Diagnostics switch (same-process A/B, the tests of the generation that is not the default).  An atomic, read once
 // per launch: the reference calls forward() from a worker thread.
-static std::atomic<int> g_attn_variant{2};      // 1: second-generation sweep (S^T in AGPRs) | 2: third generation (S^T - m in VGPRs)
+static std::atomic<int> g_attn_variant{2};      // 1: second-generation sweep (S^T in AGPRs) | 2: third generation (S^T - m in VGPRs); + 16: static parts
 extern "C" int fp_debug_attn_variant(int v) {
     return v >= 0 ? g_attn_variant.exchange(v, std::memory_order_relaxed) : g_attn_variant.load(std::memory_order_relaxed);
 }
@@ -1114,7 +1175,7 @@ __attribute__((visibility("hidden"))) int fpi_attn_combine(const float* ws, void
 }
 
 // Bytes of device workspace with which fp_attn_fwd_bf16 can split the last round's work items (any shape).
-extern "C" int64_t fp_attn_workspace_bytes(void) { return (int64_t)cu_count() * WS_FLOATS * 4; }
+extern "C" int64_t fp_attn_workspace_bytes(void) { return WS_HEAD_BYTES + (int64_t)cu_count() * WS_FLOATS * 4; }
 
 // q, k, v, o: bf16 [total_tokens, heads, 128] with arbitrary row strides (elements) and head stride 128.
 // cu_seqlens: device int32 [nseg+1] or NULL for a single segment [0, total_tokens).
@@ -1140,40 +1201,56 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     const int nqb = (max_seqlen + 255) / 256;
     const int64_t nwg = (int64_t)nqb * heads * nseg;
     FP_REQUIRE(nwg < (1ll << 31));
-    // One workgroup per CU is resident (8 waves x 238 registers): nwg items take ceil(nwg / CUs) rounds.  When the
-    // last round is at most half full and the caller gave a workspace, its items are each cut into `split` KV
-    // ranges so that the round takes 1 / split of a sweep (+ a small merge) instead of a whole one.
+    // One workgroup per CU is resident (512 registers per lane): nwg items take ceil(nwg / CUs) rounds.  With a workspace,
+    // the launch's last `tail` items are each cut into `split` KV ranges (parts), swept by separate part blocks and merged:
+    // a partly filled last round then takes 1 / split of a sweep, and - the parts being taken from a counter, not bound to
+    // blocks - the dies that are ahead take more of them (see the head of this file).  tail = the items of the partial
+    // last round when those are between an eighth and half of the CUs, else an eighth of the CUs (32 items = 256 parts on
+    // an MI355X, also when the rounds come out even: the dies still differ).
     const int ncu = cu_count();
-    int nwg_full = (int)nwg, split = 1;
-    const int tail = (int)(nwg % ncu);
-    if (workspace && nwg > ncu && tail > 0 && tail <= ncu / 2) {
+    const int variant = g_attn_variant.load(std::memory_order_relaxed);      // read once per launch
+    const bool static_parts = (variant & 16) != 0;     // diagnostics (A/B): round 2's split - one block per part, only a partial round <= half the CUs is split
+    int nwg_full = (int)nwg, split = 1, tail = 0;
+    if (workspace && nwg > ncu && ncu >= 8 && !(static_parts && (nwg % ncu == 0 || nwg % ncu > ncu / 2))) {
+        const int r = (int)(nwg % ncu), base = ncu / 8;
+        tail = static_parts ? r : ((r > base && r <= ncu / 2) ? r : base);
         split = ncu / tail < 8 ? ncu / tail : 8;
-        if ((int64_t)tail * split * WS_FLOATS * 4 <= workspace_bytes && ((uintptr_t)workspace & 15) == 0)
+        if ((int64_t)tail * split * WS_FLOATS * 4 + WS_HEAD_BYTES <= workspace_bytes && ((uintptr_t)workspace & 15) == 0 && split >= 2)
             nwg_full = (int)nwg - tail;
         else if (workspace_required)
-            return (int)hipErrorInvalidValue;       // the fixed scratch cannot hold this device's last round
+            return (int)hipErrorInvalidValue;       // the fixed scratch cannot hold this device's parts
         else
-            split = 1;
+            split = 1, tail = 0;
     }
-    const int64_t grid = nwg_full + (int64_t)(nwg - nwg_full) * split;
+    const int n_parts = (int)(nwg - nwg_full) * split;
+    // three part blocks per part: a die 8 % ahead of the slowest one takes about twice its round-robin share
+    const int64_t grid = nwg_full + (int64_t)n_parts * (static_parts ? 1 : PART_BLOCKS_PER_PART);
+    FP_REQUIRE(grid < (1ll << 31));
+    int* counter = n_parts && !static_parts ? (int*)workspace : nullptr;
+    float* partials = n_parts ? (float*)((char*)workspace + WS_HEAD_BYTES) : nullptr;
+    if (counter) {
+        hipError_t e = hipMemsetAsync(counter, 0, sizeof(int), (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     // defer-max threshold.  Second generation: 2^8 (P <= 256 before the bf16 rounding, the O rescale runs only when a
     // row's max grows by more than 8 in the log2 domain).  Third generation: 2^60 - the threshold only has to keep
     // fp32 from overflowing (P <= 2^60, row sums and O below 2^60 * keys * |v|): bf16 and fp32 keep their relative
     // precision at any magnitude, and a stale m never makes a P smaller than the true max would
     {
-        const bool gen2 = g_attn_variant.load(std::memory_order_relaxed) == 1;
+        const bool gen2 = (variant & 3) == 1;
         auto kern = gen2 ? attn_w64_kernel<8> : attn_v3_kernel<60>;
         const int lds = (gen2 ? 6 : 7) * KBUF;      // K ring of 3 slots + V ring of 3 (second generation) or 4 slots
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         kern<<<dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream>>>(
             (const bf16*)q, (const bf16*)k, (const bf16*)v, (bf16*)o, q_row_stride, k_row_stride, v_row_stride,
-            o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, (float*)workspace);
+            o_row_stride, cu_seqlens, nseg, total_tokens, heads, nqb, scale_log2e, nwg_full, split, partials, n_parts,
+            counter);
     }
     FP_CHECK_LAUNCH();
     if (nwg_full < nwg)
         attn_combine_kernel<<<dim3((unsigned)((nwg - nwg_full) * 16)), dim3(256), 0, (hipStream_t)stream>>>(
-            (const float*)workspace, (bf16*)o, o_row_stride, cu_seqlens, total_tokens, heads, nqb, nwg_full, split);
+            partials, (bf16*)o, o_row_stride, cu_seqlens, total_tokens, heads, nqb, nwg_full, split);
     FP_CHECK_LAUNCH();
     return 0;
 }
@@ -1193,7 +1270,7 @@ extern "C" int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, voi
 // In host code `scratch` is only a stand-in for the symbol: its per-device address comes from hipGetSymbolAddress,
 // once per device, and only that address is handed to kernels.
 constexpr int SCRATCH_PARTIALS = 256;           // one partial per CU of an MI355X: 256 x 133 120 B = 32.5 MiB
-static __device__ __align__(256) float scratch[(size_t)SCRATCH_PARTIALS * WS_FLOATS];
+static __device__ __align__(256) float scratch[WS_HEAD_BYTES / 4 + (size_t)SCRATCH_PARTIALS * WS_FLOATS];
 constexpr int SCRATCH_MAX_DEVICES = 64;
 static float* g_scratch_ptr[SCRATCH_MAX_DEVICES];
 static std::mutex g_scratch_mu;
@@ -1215,7 +1292,7 @@ static int scratch_for_current_device(float** out) {
     return 0;
 }
 
-extern "C" int64_t fp_attn_static_scratch_bytes(void) { return (int64_t)SCRATCH_PARTIALS * WS_FLOATS * 4; }
+extern "C" int64_t fp_attn_static_scratch_bytes(void) { return WS_HEAD_BYTES + (int64_t)SCRATCH_PARTIALS * WS_FLOATS * 4; }
 
 extern "C" int fp_attn_fwd_bf16_static(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
                                        int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
@@ -1225,7 +1302,8 @@ extern "C" int fp_attn_fwd_bf16_static(const void* q, const void* k, const void*
     const int e = scratch_for_current_device(&ptr);
     if (e) return e;
     // every partial the kernels read is written by the same call first (attn_*_kernel stores O, m, l of each part
-    // before attn_combine_kernel runs), so nothing in the array has to start at zero
+    // before attn_combine_kernel runs); the part counter at the array's start is cleared by the launcher (a memset node
+    // on the stream: no allocation)
     return attn_launch(q, k, v, o, q_row_stride, k_row_stride, v_row_stride, o_row_stride, cu_seqlens, nseg, max_seqlen,
                        total_tokens, heads, head_dim, softmax_scale, ptr, fp_attn_static_scratch_bytes(), true, stream);
 }
@@ -1233,5 +1311,9 @@ extern "C" int fp_attn_fwd_bf16_static(const void* q, const void* k, const void*
 #ifdef FP_V3_DIAG
 extern "C" int fp_attn_dbg_read(unsigned long long* out4) {
     return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(fp_attn_dbg), sizeof(unsigned long long) * 4);
+}
+extern "C" int fp_attn_tl_read(unsigned long long* out, int n_workgroups) {
+    if (n_workgroups > FP_TL_MAX) n_workgroups = FP_TL_MAX;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fp_attn_tl), sizeof(unsigned long long) * 5 * n_workgroups);
 }
 #endif

@@ -1019,11 +1019,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             if self.proj_out.weight.dtype != torch.float32:
                 self.proj_out.to(dtype=torch.float32)
                 self._packed = P          # proj_out is not part of the fused buffers
-            head = getattr(P, "head32", None)
-            if head is None or head[0] is not self.proj_out.weight:
-                w32 = self.proj_out.weight.detach()
-                w16 = w32.to(BF16)
-                head = P.head32 = (self.proj_out.weight, w16.contiguous(), bool((w16.float() == w32).all()))
+            head = getattr(P, "head32", None)       # (fp32 weights it was made from - held, so their address stays
+            w32 = self.proj_out.weight.detach()     #  theirs -, bf16 copy, whether the copy is exact)
+            ver = None if w32.is_inference() else w32._version      # (made under inference_mode: no version counter)
+            if head is None or head[0].data_ptr() != w32.data_ptr() or head[3] != ver:
+                w16 = w32.to(BF16).contiguous()
+                head = P.head32 = (w32, w16, bool((w16.float() == w32).all()), ver)
             if head[2]:
                 out = ops.gemm_f32out(head_in, head[1], self.proj_out.bias.detach().float().contiguous())
             else:

@@ -391,3 +391,35 @@ def test_gemm_with_k2_in_its_epilogue_is_bit_identical_to_the_two_passes(layout,
                     wq_txt=wq_txt, wk_txt=wk_txt)
     assert torch.isfinite(got.float()).all()
     assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
+
+
+def test_layernorm_affine_matches_torch_layer_norm():
+    """K3's affine form (the token refiner's nn.LayerNorm, ref hunyuan_video_packed.py:264, 273 through
+    dit_common.py:9-10): fp32 arithmetic, one rounding - against F.layer_norm in fp32 on the same bf16 values."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    for rows, cols in ((512, 3072), (37, 256), (5, 4096)):
+        big = torch.randn(rows, cols + 64, generator=g, device=DEV).to(BF)
+        x = big[:, :cols]                                                   # row-strided view
+        w = (1 + 0.3 * torch.randn(cols, generator=g, device=DEV)).to(BF)
+        w[:3] = torch.tensor([0.0101, -2.5, 5.3], device=DEV).to(BF)       # weights far from 1 (w - 1 is not a bf16 value)
+        b = torch.randn(cols, generator=g, device=DEV).to(BF)
+        ref = torch.nn.functional.layer_norm(x.float(), (cols,), w.float(), b.float(), 1e-6)
+        got = ops.layernorm_affine(x, w, b, 1e-6)
+        assert got.dtype == BF and tuple(got.shape) == (rows, cols)
+        assert rel_l2(got, ref) < 3e-3
+        assert (got.float() - ref).abs().max().item() <= ref.abs().max().item() * 2 ** -7
+
+
+def test_gemm_bf16_with_fp32_output_is_the_fp32_linear():
+    """The fp32 head (ref :1048-1053: activations and weights upcast to fp32, then nn.Linear): bf16 operands hold the same
+    values as their fp32 copies and bf16 x bf16 products are exact in fp32, so K5 with fp32 output must agree with the fp32
+    linear to summation order (1e-6 relative), far inside what a bf16-rounded output would give (4e-3)."""
+    g = torch.Generator(device=DEV).manual_seed(22)
+    for M, N, K in ((14400, 64, 3072), (300, 64, 256), (1000, 512, 512)):
+        a = torch.randn(M, K, generator=g, device=DEV).to(BF)
+        w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(BF)
+        b = torch.randn(N, generator=g, device=DEV)
+        got = ops.gemm_f32out(a, w, b)
+        ref = a.double() @ w.double().T + b.double()
+        assert got.dtype == torch.float32 and rel_l2(got, ref) < 2e-6
+        assert rel_l2(ops.gemm_f32out(a, w, None), ref - b.double()) < 2e-6

@@ -9,10 +9,10 @@ mkdir -p $CS/probe
 if [ "$1" = build ]; then
   FLAGS=$(sed -n 's/^FLAGS_attn_fwd = //p' $CS/Makefile)
   for m in $2; do
-    ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $FLAGS -DFP_V3_SKIP=$m -DFP_V3_DIAG \
+    ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $FLAGS -DFP_V3_SKIP=$m -DFP_V3_DIAG=${DIAG:-1} \
         -c $CS/attn_fwd.hip -o $CS/probe/attn_skip$m.o
       # the compiler must not touch AGPRs (they are addressed by number from inline asm): check the assembly
-      /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $FLAGS -DFP_V3_SKIP=$m -DFP_V3_DIAG -S --cuda-device-only \
+      /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $FLAGS -DFP_V3_SKIP=$m -DFP_V3_DIAG=${DIAG:-1} -S --cuda-device-only \
         $CS/attn_fwd.hip -o $CS/probe/attn_skip$m.s 2>/dev/null
       n=$(awk '/^_ZN.*attn_v3_kernel/{k=1} /amdhsa_kernel.*attn_v3/{k=0} /ASMSTART/{a=1} /ASMEND/{a=0} { if(k && !a && $0 ~ /v_accvgpr|scratch_/) c++ } END{print c+0}' $CS/probe/attn_skip$m.s)
       rm -f $CS/probe/attn_skip$m.s

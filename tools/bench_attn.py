@@ -25,7 +25,12 @@ if os.environ.get("ATTN_VARIANT"):                     # 1: second-generation sw
     from framepack_amd import lib as _fplib
     _fplib.load().fp_debug_attn_variant(int(os.environ["ATTN_VARIANT"]))
 attn = ops.attention_fp8 if os.environ.get("FP8") else ops.attention       # FP8=1: the e4m3 variant (quantisation included)
+AB = [int(x) for x in os.environ.get("ATTN_AB", "").split(",") if x]      # e.g. ATTN_AB=18,2: alternate the variants run by run
 for variant in range(int(os.environ.get("REPEAT", "2"))):
+    if AB:
+        from framepack_amd import lib as _fplib
+        _fplib.load().fp_debug_attn_variant(AB[variant % len(AB)])
+        print(f"variant {AB[variant % len(AB)]}:", end=" ")
     for _ in range(3):
         attn(q, k, v, H, out=out)
     torch.cuda.synchronize()
