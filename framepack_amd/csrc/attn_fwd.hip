@@ -544,7 +544,8 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(const bf16* __restrict
 // then wrong): 1 exp2/pack/sum items, 2 LDS fragment reads, 4 LDS-DMA issues, 8 the per-tile barrier, 16 P.V MFMAs,
 // 32 Q.K MFMAs, 128 never take the slow path after the first tile (for builds whose scores are garbage), 256 every V^T
 // fragment by ONE ds_read_b128 (what a V delivered pre-transposed would cost), 512 the barrier in every other tile only
-// (what 128-key iterations would save of it).  The shipped library is built without it.
+// (what 128-key iterations would save of it), 1024 no row-sum adds (the most that row sums through an MFMA against a
+// ones block could save, before that MFMA's own cost).  The shipped library is built without it.
 #ifndef FP_V3_SKIP
 #define FP_V3_SKIP 0
 #endif
@@ -773,8 +774,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
             u32x2 h[2];
             bf16x8 v;
         } a;
-        if constexpr (FP_V3_SKIP & 256) {
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4) * 64));
+        if constexpr (FP_V3_SKIP & 256) {      // (timing only: a conflict-free b128 pattern - the K image's - inside the V slot;
+            //  needs the registers that bit 4 frees: build 4 + 256 and compare with 4)
+            const unsigned a = (vbase - v_lane_off) + (k_lane_base ^ (unsigned)((S4 * 2 + (D >> 1)) << 5));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a), "n"((D & 1) * 8192));
             return;
         }
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a.h[0]) : "v"(vbase), "n"(D * (KVBLK * 64) + (16 * S4) * 64));
@@ -837,8 +840,10 @@ __global__ __launch_bounds__(256, 1) void attn_v3_kernel(const bf16* __restrict_
         // row-sum add of exp h and, with the second value of a pair, the pack into its P^T dword
         auto finish_exp = [&](auto H_) __attribute__((always_inline)) {
             constexpr int h = H_, i = h >> 1, s4 = i >> 3, rb = (i >> 2) & 1, dw = i & 3;
-            rs[rb] += ev[h & 3];
-            asm volatile("" : "+v"(rs[rb]));
+            if constexpr (!(FP_V3_SKIP & 1024)) {
+                rs[rb] += ev[h & 3];
+                asm volatile("" : "+v"(rs[rb]));
+            }
             if constexpr (h & 1) {
                 union {
                     unsigned u[4];

@@ -1,5 +1,7 @@
 """Same-process A/B of kernel generations inside the 13B forward (ms per forward, alternating).
-usage: ab_model.py [gemm|attn] [fp8]      (fp8: the opt-in e4m3 mode, linears and attention)"""
+usage: ab_model.py [gemm|attn] [fp8]      (fp8: the opt-in e4m3 mode, linears and attention)
+AB_VARIANTS=3,1 (env): the two values handed to the fp_debug_*_variant switch instead of 0, 1
+(gemm: 3 = static tile schedule, 1 = tiles from the counters; attn: 18 = one block per part, 2 = parts from the counter)"""
 import os
 import sys
 import time
@@ -26,7 +28,7 @@ with torch.inference_mode():
     for _ in range(2):
         model(return_dict=False, **kw)
     for rep in range(3):
-        for v in (0, 1):
+        for v in [int(x) for x in os.environ.get("AB_VARIANTS", "0,1").split(",")]:
             (L.fp_debug_attn_variant if (len(sys.argv) > 1 and sys.argv[1] == "attn") else L.fp_debug_gemm_variant)(v)
             model(return_dict=False, **kw)
             torch.cuda.synchronize()
@@ -34,4 +36,4 @@ with torch.inference_mode():
             for _ in range(3):
                 out = model(return_dict=False, **kw)[0]
             torch.cuda.synchronize()
-            print(f"rep {rep} {sys.argv[1] if len(sys.argv) > 1 else 'gemm'} variant {v} ({'4-wave' if v else '8-wave'}): {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)
+            print(f"rep {rep} {sys.argv[1] if len(sys.argv) > 1 else 'gemm'} variant {v}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)

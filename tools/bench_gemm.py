@@ -22,7 +22,13 @@ SHAPES = [  # (M, N, K, epilogue, name)
     (4096, 4096, 4096, ops.EPI_BIAS, "4096^3"),
     (8192, 8192, 8192, ops.EPI_BIAS, "8192^3"),
 ]
-for M, N, K, epi, name in SHAPES:
+AB = [int(x) for x in os.environ.get("GEMM_AB", "").split(",") if x]     # e.g. GEMM_AB=3,1: static vs dynamic tile schedule
+from framepack_amd import lib as _fplib  # noqa: E402
+for M, N, K, epi, name in [sh for sh in SHAPES for _ in range(max(1, 2 * len(AB)))]:
+    if AB:
+        AB.append(AB.pop(0))
+        _fplib.load().fp_debug_gemm_variant(AB[-1])
+        name = f"[variant {AB[-1]}] {name}"
     a = (torch.rand(M, K, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
     w = (torch.rand(N, K, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
     b = (torch.rand(N, generator=g, device=dev) * 2 - 1).to(torch.bfloat16)
@@ -54,5 +60,5 @@ for M, N, K, epi, name in SHAPES:
         ref = kw["resid"][rows].double() + kw["gate"].double() * ref
     err = ((out[rows].double() - ref).norm() / ref.norm()).item()
     fl = 2.0 * M * N * K
-    print(f"{name:32s} M={M:6d} N={N:6d} K={K:6d}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s "
+    print(f"{name:44s} M={M:6d} N={N:6d} K={K:6d}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s "
           f"({fl / ms / 1e9 / 25:.1f}% of 2.5 PF)  rel err {err:.2e}", flush=True)
