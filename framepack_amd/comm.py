@@ -42,34 +42,67 @@ def all_gather_padded(x: torch.Tensor, sizes: Sequence[int], group=None) -> List
     return [out[r * n:r * n + sizes[r]] for r in range(world)]
 
 
-def neighbour_exchange(send_up: Optional[torch.Tensor], send_down: Optional[torch.Tensor],
-                       group=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """Halo exchange along a chain of ranks: rank r sends `send_up` to rank r - 1 and `send_down` to rank r + 1 (None
-    at the ends of the chain) and receives (from_up, from_down) of the same shapes from those neighbours.  All four
-    transfers are posted before any is waited for."""
+class _Halo:
+    """Handle of a posted halo exchange: `wait()` -> (from_up, from_down)."""
+
+    def __init__(self, works, bufs, like_up, like_down):
+        self._works, self._bufs, self._like = works, bufs, (like_up, like_down)
+
+    def wait(self) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+        for w in self._works:
+            w.wait()                      # RCCL: the current stream waits for the communicator's; gloo: the host does
+        self._works = []
+
+        def back(key, like):
+            if like is None:
+                return None
+            b = self._bufs[key]
+            return b.to(like.device) if b.device != like.device else b
+        return back("up", self._like[0]), back("down", self._like[1])
+
+
+def neighbour_exchange_start(send_up: Optional[torch.Tensor], send_down: Optional[torch.Tensor], group=None,
+                             cache: Optional[dict] = None) -> _Halo:
+    """Post the halo exchange along a chain of ranks and return at once: rank r sends `send_up` to rank r - 1 and
+    `send_down` to rank r + 1 (None at the ends of the chain) and receives tensors of the same shapes from those
+    neighbours.  All transfers are posted in one batch; what the caller launches before `wait()` runs while they travel
+    (on RCCL the transfers are on the communicator's stream).  cache: a dict the caller keeps - send staging and receive
+    buffers are then allocated once per shape instead of once per call (a buffer is free again when the caller has
+    consumed what `wait()` returned, which is before it posts the next exchange of that shape)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ops, bufs = [], {}
 
     def peer(r):
         return dist.get_global_rank(group, r) if group is not None else r
+
+    def buf(kind, key, like):
+        if cache is None:
+            return torch.empty_like(like)
+        k = (kind, key, tuple(like.shape), like.dtype, str(like.device))
+        b = cache.get(k)
+        if b is None:
+            b = cache[k] = torch.empty_like(like)
+        return b
     for key, t, r in (("up", send_up, rank - 1), ("down", send_down, rank + 1)):
         if t is None:
             continue
         assert 0 <= r < world
-        src = t.contiguous()
-        if _staged(src, group):
-            src = src.cpu()
-        dst = torch.empty_like(src)
+        if _staged(t, group):
+            src = t.contiguous().cpu()
+        elif t.is_contiguous():
+            src = t
+        else:
+            src = buf("send", key, torch.empty(t.shape, dtype=t.dtype, device=t.device))
+            src.copy_(t)
+        dst = buf("recv", key, src)
         bufs[key] = dst
         ops.append(dist.P2POp(dist.isend, src, peer(r), group))
         ops.append(dist.P2POp(dist.irecv, dst, peer(r), group))
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return _Halo(works, bufs, send_up, send_down)
 
-    def back(key, like):
-        if like is None:
-            return None
-        b = bufs[key]
-        return b.to(like.device) if b.device != like.device else b
-    return back("up", send_up), back("down", send_down)
+
+def neighbour_exchange(send_up: Optional[torch.Tensor], send_down: Optional[torch.Tensor],
+                       group=None) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """`neighbour_exchange_start(...).wait()`: the blocking form."""
+    return neighbour_exchange_start(send_up, send_down, group).wait()

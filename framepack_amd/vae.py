@@ -21,6 +21,7 @@ oracle/vae_oracle.py (see its header).  There is no CPU path: `decode` / `encode
 """
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -151,6 +152,11 @@ def _pad_to(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+# FRAMEPACK_VAE_HALO_OVERLAP=0: the tiled decode exchanges the border rows BEFORE each convolution and computes on the
+# extended band (round 2's form) instead of overlapping the exchange with the convolution (_conv_b)
+_HALO_OVERLAP = os.environ.get("FRAMEPACK_VAE_HALO_OVERLAP", "1") != "0"
+
+
 class DecoderOutput(SimpleNamespace):
     pass
 
@@ -168,9 +174,10 @@ class _Bands:
         keeps the queries of its band.
     Time is not split (the causal convolutions need every earlier frame) and neither is W."""
 
-    def __init__(self, group, H: int):
+    def __init__(self, group, H: int, cache: Optional[dict] = None):
         import torch.distributed as dist
         self.group = group
+        self.cache = cache                 # halo buffers, allocated once per shape (comm.neighbour_exchange_start)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         if H < self.world:
             raise ValueError(f"{H} latent rows cannot be tiled over {self.world} ranks")
@@ -186,6 +193,12 @@ class _Bands:
         fu, fd = neighbour_exchange(x[:, :1] if self.top else None, x[:, -1:] if self.bot else None, self.group)
         parts = ([fu] if self.top else []) + [x] + ([fd] if self.bot else [])
         return torch.cat(parts, dim=1) if len(parts) > 1 else x
+
+    def exchange_start(self, x: torch.Tensor):
+        """Post the exchange of the band's border rows; `.wait()` -> (row from above, row from below)."""
+        from .comm import neighbour_exchange_start
+        return neighbour_exchange_start(x[:, :1] if self.top else None, x[:, -1:] if self.bot else None, self.group,
+                                        self.cache)
 
     def crop(self, y_ext: torch.Tensor, up_h: int) -> torch.Tensor:
         """Cut the rows computed from a halo row off a convolution's output (up_h output rows per input row)."""
@@ -424,16 +437,47 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         return ops.groupnorm_apply(x, st, W[name + ".g"], W[name + ".b"], g, silu, out)
 
     def _conv_b(self, B: _Bands, W, name: str, x: torch.Tensor, up=(1, 1, 1), resid: Optional[torch.Tensor] = None):
-        xe = B.extend(x)
-        re = None
-        if resid is not None:                    # the skip is added in the kernel's epilogue, as on one GPU: give it
-            re = resid                           # the extended shape (halo rows: anything finite, they are cut off)
-            if B.top or B.bot:
+        """A 3x3x3 convolution over this rank's band with the neighbours' border rows, the exchange overlapped: the
+        border rows are posted, the convolution runs over the band as it is (its first and last output rows, computed
+        against the kernel's clamp where a neighbour's row belongs, are provisional), and when the rows have arrived the
+        `up_h` output rows next to each neighbour are recomputed from a slab of three input rows (neighbour's row, border
+        row, the row behind it) and written over the provisional ones.  Same kernel, same operands per output voxel as
+        the convolution over the extended band (FRAMEPACK_VAE_HALO_OVERLAP=0 runs that one: exchange, then compute)."""
+        w, b = W[name + ".w"], W[name + ".b"]
+        if not (B.top or B.bot):
+            return ops.conv3d_causal(x, w, b, up=up, resid=resid)
+        if not _HALO_OVERLAP:
+            xe = B.extend(x)
+            re = None
+            if resid is not None:                # the skip is added in the kernel's epilogue, as on one GPU: give it
                 re = torch.zeros((resid.shape[0], xe.shape[1] * up[1], resid.shape[2], resid.shape[3]), dtype=F16,
-                                 device=resid.device)
+                                 device=resid.device)      # the extended shape (halo rows: zeros, they are cut off)
                 r0 = up[1] if B.top else 0
                 re[:, r0:r0 + resid.shape[1]] = resid
-        return B.crop(ops.conv3d_causal(xe, W[name + ".w"], W[name + ".b"], up=up, resid=re), up[1])
+            return B.crop(ops.conv3d_causal(xe, w, b, up=up, resid=re), up[1])
+        halo = B.exchange_start(x)
+        y = ops.conv3d_causal(x, w, b, up=up, resid=resid)         # runs while the border rows travel
+        fu, fd = halo.wait()
+        u, Hb = up[1], x.shape[1]
+
+        def fix(rows, mid: int, y0: int):
+            """Recompute the output rows of slab row `mid` and write them to y[:, y0 : y0 + u]."""
+            slab = torch.cat(rows, dim=1)
+            rs = None
+            if resid is not None:
+                rs = torch.zeros((resid.shape[0], slab.shape[1] * u, resid.shape[2], resid.shape[3]), dtype=F16,
+                                 device=resid.device)
+                rs[:, mid * u:(mid + 1) * u] = resid[:, y0:y0 + u]
+            ys = ops.conv3d_causal(slab, w, b, up=up, resid=rs)
+            y[:, y0:y0 + u] = ys[:, mid * u:(mid + 1) * u]
+        if Hb == 1:                              # one row: both neighbours (where there are any) in one slab
+            fix(([fu] if B.top else []) + [x] + ([fd] if B.bot else []), 1 if B.top else 0, 0)
+            return y
+        if B.top:
+            fix([fu, x[:, :2]], 1, 0)
+        if B.bot:
+            fix([x[:, -2:], fd], 1, (Hb - 1) * u)
+        return y
 
     def _resnet_b(self, B: _Bands, W, name: str, h: torch.Tensor) -> torch.Tensor:
         a = self._gn_b(B, W, name + ".norm1", h)
@@ -471,7 +515,9 @@ class AutoencoderKLHunyuanVideo(nn.Module):
         cfg = self.config
         lat = cfg.latent_channels
         _, _, T, H, Wd = z.shape
-        B = _Bands(self._tp_group, H)
+        if not hasattr(self, "_halo_bufs"):
+            self._halo_bufs = {}
+        B = _Bands(self._tp_group, H, self._halo_bufs)
         x = torch.zeros(T, B.hi - B.lo, Wd, W["pq.w"].shape[0], dtype=F16, device=z.device)
         x[..., :lat] = z[0, :, :, B.lo:B.hi].permute(1, 2, 3, 0).to(F16)
         x = ops.gemm(x.reshape(-1, x.shape[-1]), W["pq.w"], W["pq.b"]).reshape(x.shape)
@@ -594,6 +640,23 @@ class AutoencoderKLHunyuanVideo(nn.Module):
             raise RuntimeError("enable_window_parallel and enable_tile_parallel exclude each other: a decode is split "
                                "either by windows or by bands of rows")
         self._tp_group = group if group is not None else dist.group.WORLD
+
+    def enable_hybrid_parallel(self, window_groups: int) -> None:
+        """Windows AND bands (BASELINE config 5: 11 windows of a 5 s 720p clip on 8 GPUs): the world's P ranks form
+        `window_groups` groups of P / window_groups ranks; window n is decoded by group n % window_groups, each of its
+        ranks on one band of rows (`enable_tile_parallel` inside the group), and then handed to the other groups (rank
+        b of a group broadcasts to rank b of every other group: `enable_window_parallel` across the groups).  Where a
+        frame has few rows per rank (90 latent rows over 8 ranks) or a clip few windows per rank, the product of the
+        two fits better than either.  Every rank calls decode() with the same latents and gets the same frames.
+        Collective: every rank of the world must call it (it creates the sub-groups)."""
+        import torch.distributed as dist
+        P, r = dist.get_world_size(), dist.get_rank()
+        if window_groups < 1 or P % window_groups:
+            raise ValueError(f"{P} ranks do not split into {window_groups} window groups")
+        nb = P // window_groups
+        band = [dist.new_group([g * nb + b for b in range(nb)]) for g in range(window_groups)]
+        wins = [dist.new_group([g * nb + b for g in range(window_groups)]) for b in range(nb)]
+        self._tp_group, self._wp_group = band[r // nb], wins[r % nb]
 
     def _framewise(self, z: torch.Tensor, tile_fn) -> torch.Tensor:
         """diffusers' _temporal_tiled_decode: windows of t_min+1 latent frames at stride t_stride, the first

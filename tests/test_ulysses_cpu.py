@@ -25,6 +25,7 @@ def _worker(rank, world, port, n_img_total, n_txt, heads, strided, chunks, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(max(1, 8 // world))                  # (8 CPUs here: the ranks share them)
     try:
         d = heads * 128
         g = torch.Generator("cpu").manual_seed(0)

@@ -20,6 +20,7 @@ def _worker(rank, world, port, T, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(max(1, 8 // world))                  # (8 CPUs here: the ranks share them)
     try:
         cfg = VO.VAEConfig(**CFG)
         P = VO.random_state_dict(cfg, seed=3)
