@@ -229,7 +229,7 @@ def main():
     # HBM-side bytes per launch of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh) - valid for the workload shape only
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r2_q_attn_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r3_h_attn_hbm_traffic.json")
     if args.config == "13b" and world == 1 and rows == 19385 and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = round(json.load(f)["traffic_bytes_per_launch"])
@@ -240,7 +240,7 @@ def main():
                 else "attn_v3_kernel<60> (K1 flash attention, bf16 MFMA 32x32x16, one wave per SIMD, S^T - m accumulated in VGPRs)", "bound": "mfma",
                 "achieved": round(achieved / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_unit": "bytes per launch (PMC, profiles/r2_q_attn_hbm_traffic.json; algorithmic 476 MB)",
+                "traffic_unit": "bytes per launch (PMC, profiles/r3_h_attn_hbm_traffic.json; algorithmic 476 MB)",
                 "launches": len(att_ms), "avg_launch_ms": round(att_avg_s * 1e3, 4),
                 "flops_per_launch": flops_per_launch,
                 "share_of_step_time": round(sum(att_ms) / 1e3 / elapsed, 4)}

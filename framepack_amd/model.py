@@ -279,7 +279,10 @@ class ClipVisionProjection(nn.Module):                  # ref :655-663
         self.down = nn.Linear(out_channels * 3, out_channels)
 
     def forward(self, x):
-        return self.down(F.silu(self.up(x)))
+        """down(silu(up(x))) on K5 (once per section: the result is cached across steps, model._cached)."""
+        rows = x.reshape(-1, x.shape[-1])
+        h = F.silu(ops.gemm(rows, self.up.weight.detach(), self.up.bias.detach()))
+        return ops.gemm(h, self.down.weight.detach(), self.down.bias.detach()).reshape(x.shape[:-1] + (self.down.out_features,))
 
 
 class HunyuanVideoPatchEmbed(nn.Module):                # ref :666-669
