@@ -34,9 +34,12 @@ int fp_abi_version(void);
  * for one segment over all rows (the B == 1 branch :927-932).  max_seqlen >= the longest segment.
  * `o` may alias `q`.  o needs 8-byte alignment / stride % 4 only.  K and V must each span < 4 GiB.
  * workspace (optional, may be NULL): fp_attn_workspace_bytes() bytes of device memory, 16-byte aligned.  With
- * it, when the work items (heads x 256-row query blocks) do not fill the last round of the chip, that round's
- * items are swept in parallel KV ranges and merged (same result to fp32 rounding); without it the call is
- * unchanged but the last round runs partly idle.  The library allocates nothing either way. */
+ * it, the launch's last work items (heads x 256-row query blocks; an eighth of the CUs' worth, or the partial last
+ * round) are swept as parallel KV ranges ("parts") and merged (same result to fp32 rounding), and the parts are
+ * taken from a counter at the start of the workspace, so the XCDs that finish their whole sweeps first take more of
+ * them (the dies of one chip differ by 7-8 % in speed); without it the call is unchanged but the launch ends with
+ * its slowest die and a partly idle last round.  The call clears the counter on `stream` (a memset node: no
+ * allocation); one workspace must not serve two calls that can overlap (use one per stream). */
 int64_t fp_attn_workspace_bytes(void);
 int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o,
                      int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride,
@@ -243,7 +246,8 @@ int fp_softmax_framecausal_f32_f16(void* s, int rows, int cols, int64_t ld, int 
  * Select the kernel generation used by fp_gemm_bf16 / fp_attn_fwd_bf16 for same-process A/B measurements
  * (tools/ab_model.py) and for the tests of the generation that is not the default.  GEMM: 0 = first generation (8 waves
  * per workgroup), 1 = second (one wave per SIMD; default).  Attention: 1 = second generation (S^T in AGPRs), 2 = third
- * (S^T - m accumulated in VGPRs; default).  v < 0 only queries.  Returns the previous value.  Process-wide; the
+ * (S^T - m accumulated in VGPRs; default); + 16 = one block per split part and only a partial last round split (round
+ * 2's schedule; the default takes the parts from a counter).  v < 0 only queries.  Returns the previous value.  Process-wide; the
  * switches are atomics read once per launch, so a change never tears a launch in flight on another thread.
  * fp_gemm_fp8_bf16 follows the GEMM switch too.  For the GEMM, v >> 4 (when non-zero) overrides the number of row
  * tiles per group of the tile walk (tools/gemm_xp.py scans it: FP_GEMM_VARIANT = 1 + 16 * gm). */
