@@ -68,7 +68,10 @@ int fp_attn_fwd_bf16_static(const void* q, const void* k, const void* v, void* o
  * v, taken over ALL rows; V stored transposed in the kernel's key order, every segment with its own grid of 64-key
  * tiles - and then runs the sweep.  The result differs from fp_attn_fwd_bf16's by a few per cent (3 mantissa bits).
  * workspace: device memory, 256-byte aligned, at least fp_attn_fp8_varlen_workspace_bytes(total_tokens, heads, nseg,
- * max_seqlen) bytes (fp_attn_fp8_workspace_bytes(total_tokens, heads) for the one-segment call); o may alias q. */
+ * max_seqlen) bytes (fp_attn_fp8_workspace_bytes(total_tokens, heads) for the one-segment call); o may alias q.
+ * PRECONDITION (not checked: cu_seqlens lives on the device): max_seqlen >= every segment's length.  A longer segment is
+ * swept over its first ceil(max_seqlen / 64) key tiles only and its query rows past ceil(max_seqlen / 256) * 256 are not
+ * written (fp_attn_fwd_bf16 under the same violation reads all keys but also leaves those rows unwritten). */
 int64_t fp_attn_fp8_workspace_bytes(int total_tokens, int heads);
 int fp_attn_fwd_fp8(const void* q, const void* k, const void* v, void* o, int64_t q_row_stride,
                     int64_t k_row_stride, int64_t v_row_stride, int64_t o_row_stride, int total_tokens, int heads,

@@ -70,6 +70,8 @@ CASES = {
     "odd_text": dict(seed=8, frames_latent=2, height=96, width=160, n_text=1, sigma=0.05),
     # BASELINE config 3's shape: the 640 x 640 x 33-frame section with 256 text tokens, S = 19 385
     "config3": dict(seed=31337, frames_latent=9, height=640, width=640, n_text=256, sigma=0.7),
+    # BASELINE config 4's stress point: latent window 33 at 640 x 640, the longest packed sequence (S = 57 785)
+    "config4": dict(seed=31337, frames_latent=33, height=640, width=640, n_text=256, sigma=0.7),
 }
 
 
@@ -90,13 +92,15 @@ def test_sequence_parallel_forward_equals_single_gpu(case, teacache, fp8_attenti
         assert split_is_bit_identical
 
 
-def test_sequence_parallel_forward_at_13b_width_and_product_length():
-    """BASELINE config 3 as far as one GPU goes: 13B-width blocks (1 double + 1 single) at S = 19 385, two ranks (12 heads
-    each: `pick_chunks` = 2, the single block's in-projection split around the exchange) against the same model's
-    single-GPU forward.  The scaling curve itself is unmeasured here (one GPU)."""
+@pytest.mark.parametrize("case", ["config3", "config4"], ids=["config3_S19385", "config4_max_packed_S57785"])
+def test_sequence_parallel_forward_at_13b_width_and_product_length(case):
+    """BASELINE configs 3 and 4 as far as one GPU goes: 13B-width blocks (1 double + 1 single) at S = 19 385 and at the
+    longest packed sequence (window 33: S = 57 785), two ranks (12 heads each: `pick_chunks` = 2, the single block's
+    in-projection split around the exchange) against the same model's single-GPU forward.  The scaling curve itself is
+    unmeasured here (one GPU)."""
     world = 2
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), CASES["config3"], False, False, 24, None, ret, True), nprocs=world,
+    mp.spawn(_worker, args=(world, _free_port(), CASES[case], False, False, 24, None, ret, True), nprocs=world,
              join=True)
     assert len(ret) == world
     for err, same_counts, split_is_bit_identical in ret.values():

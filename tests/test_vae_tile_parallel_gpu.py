@@ -20,7 +20,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, cfg_kw, shape, ret):
+def _worker(rank, world, port, cfg_kw, shape, ret, with_oracle=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, cfg_kw, shape, ret):
         mse = ((tiled.double() - single.double()) ** 2).mean().item()
         out = dict(shape=tuple(tiled.shape), max_diff=(tiled - single).abs().max().item(), same=same,
                    psnr=10 * math.log10(4.0 / max(mse, 1e-30)))
-        if rank == 0:
+        if rank == 0 and with_oracle:
             want = VO.vae_decode({k: v.float() for k, v in P16.items()}, cfg, z.to(H16).float())
             out["psnr_oracle"] = 10 * math.log10(4.0 / max(((tiled.double() - want.double()) ** 2).mean().item(), 1e-30))
         ret[rank] = out
@@ -71,3 +71,15 @@ def test_tiled_decode_on_the_hip_kernels_equals_single_gpu(world, cfg_kw, shape)
         assert r["max_diff"] <= 1e-2 and r["psnr"] >= 60.0, r           # GroupNorm moments merged in another order
         assert r["same"], r
     assert ret[0]["psnr_oracle"] >= 40.0, ret[0]
+
+
+def test_tiled_decode_of_the_720p_stress_clip_equals_single_gpu():
+    """BASELINE config 5's VAE half as far as one GPU goes: latents [1, 16, 31, 90, 160] (121 frames of 720 x 1280, 11
+    framewise windows) at the default widths, two ranks of 45 latent rows each on one MI355X, against the same process's
+    single-GPU decode.  (No oracle at this size: hours of CPU.)"""
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), FULL, (31, 90, 160), ret, False), nprocs=2, join=True)
+    assert len(ret) == 2
+    for r in ret.values():
+        assert r["shape"] == (1, 3, 121, 720, 1280)
+        assert r["max_diff"] <= 2e-2 and r["psnr"] >= 60.0 and r["same"], r
