@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     };
     // EVEN: t is even before the clamp (clamped, an even and the odd call behind it both name tile nk - 1)
     auto issue_a1 = [&](int h, int j, int t, auto EVEN) __attribute__((always_inline)) {
+#if defined(FP_PROBE_NO_A_DMA)      // timing-only probe builds (results wrong): what the A operand's LDS-DMA pieces cost
+        if (AMODE == 1 && (FP_PROBE_NO_A_DMA == 1 || j != 0)) return;      // 1: none of them; 2: one of four (what shared W taps would leave: a third)
+#endif
         t = min(t, nk - 1);
         dma16(src_a(h, j, t, EVEN), smem + (t & 1) * OP_BYTES + arow0[h][j] * 128);
     };
