@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks that all use cuda:0 and exchange over gloo (RCCL refuses two ranks on one device): "
                          "runs the multi-rank code path on a one-GPU box; the number it prints is NOT a measurement")
+    ap.add_argument("--force-sp", action="store_true",
+                    help="N == 1 only (diagnostics): a one-rank nccl group and the sequence-parallel code path on it - every "
+                         "exchange, gather and buffer of the multi-GPU path at full size, with the data movement an "
+                         "identity; the number it prints is NOT the single-GPU measurement")
     return ap.parse_args()
 
 
@@ -131,6 +135,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    elif args.force_sp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from framepack_amd import ops, sampler, synthetic
     from framepack_amd.model import HunyuanVideoTransformer3DModelPacked
@@ -153,6 +161,8 @@ def main():
         model.enable_fp8_attention()
     if world > 1:
         model.enable_sequence_parallel()
+    elif args.force_sp:
+        model.enable_sequence_parallel(force=True)
 
     kw = synthetic.make_inputs(seed=31337, frames_latent=frames_latent, height=height, width=width, n_text=args.n_text,
                                dtype=bf)
@@ -254,7 +264,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": False,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "fp8-e4m3 block linears and attention (opt-in, outside the 1e-2 parity bar)" if args.fp8 else "bf16",
-            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if args.rehearse_one_gpu else ""),
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU over gloo, not a measurement)" if args.rehearse_one_gpu else "")
+            + (" (DIAGNOSTIC: sequence-parallel path on a one-rank nccl group, not the single-GPU measurement)" if args.force_sp else ""),
             "config": {"workload": workload, "packed_tokens": S, "image_tokens": Si, "text_tokens": St,
                        "teacache": False, "parallelism": "single GPU" if world == 1 else f"ulysses-sp{world}"},
             "model_tflops_per_step": round((24 * 3072 ** 2 * S + 4 * S * S * 3072) * 60 / 1e12, 1) if args.config == "13b" else None,
@@ -270,7 +281,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config == "13b":
             line["cpu_baseline"] = cpu_baseline(Si, St, args.cpu_threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or args.force_sp:
         dist.destroy_process_group()
 
 
