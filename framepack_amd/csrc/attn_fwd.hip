@@ -1180,7 +1180,8 @@ __attribute__((visibility("hidden"))) int fpi_attn_combine(const float* ws, void
 }
 
 // Bytes of device workspace with which fp_attn_fwd_bf16 can split the last round's work items (any shape).
-extern "C" int64_t fp_attn_workspace_bytes(void) { return WS_HEAD_BYTES + (int64_t)cu_count() * WS_FLOATS * 4; }
+// (two partial slots per CU: a partial last round of up to all the CUs' worth of items can be cut at least in two)
+extern "C" int64_t fp_attn_workspace_bytes(void) { return WS_HEAD_BYTES + 2 * (int64_t)cu_count() * WS_FLOATS * 4; }
 
 // q, k, v, o: bf16 [total_tokens, heads, 128] with arbitrary row strides (elements) and head stride 128.
 // cu_seqlens: device int32 [nseg+1] or NULL for a single segment [0, total_tokens).
@@ -1208,24 +1209,38 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     FP_REQUIRE(nwg < (1ll << 31));
     // One workgroup per CU is resident (512 registers per lane): nwg items take ceil(nwg / CUs) rounds.  With a workspace,
     // the launch's last `tail` items are each cut into `split` KV ranges (parts), swept by separate part blocks and merged:
-    // a partly filled last round then takes 1 / split of a sweep, and - the parts being taken from a counter, not bound to
-    // blocks - the dies that are ahead take more of them (see the head of this file).  tail = the items of the partial
-    // last round when those are between an eighth and half of the CUs, else an eighth of the CUs (32 items = 256 parts on
-    // an MI355X, also when the rounds come out even: the dies still differ).
+    // a partly filled last round then takes about 1 / split of a sweep instead of a whole one, and - the parts being
+    // taken from a counter, not bound to blocks - the dies that are ahead take more of them (see the head of this file).
+    // tail = the items of the partial last round (r), cut as finely as the workspace's partial slots allow (at most 8
+    // ways); when that round holds an eighth of the CUs' worth or less - also none at all: the dies still differ - an
+    // eighth of the CUs' worth (32 items = 256 parts on an MI355X); when cutting the whole partial round would not pay
+    // (too few slots for r items to be cut at all, or so few ways that the parts take a sweep's time again), that eighth
+    // as well.
     const int ncu = cu_count();
     const int variant = g_attn_variant.load(std::memory_order_relaxed);      // read once per launch
     const bool static_parts = (variant & 16) != 0;     // diagnostics (A/B): round 2's split - one block per part, only a partial round <= half the CUs is split
     int nwg_full = (int)nwg, split = 1, tail = 0;
-    if (workspace && nwg > ncu && ncu >= 8 && !(static_parts && (nwg % ncu == 0 || nwg % ncu > ncu / 2))) {
+    const int64_t slots = workspace && ((uintptr_t)workspace & 15) == 0 ? (workspace_bytes - WS_HEAD_BYTES) / ((int64_t)WS_FLOATS * 4) : 0;
+    if (slots > 0 && nwg > ncu && ncu >= 8 && !(static_parts && (nwg % ncu == 0 || nwg % ncu > ncu / 2))) {
         const int r = (int)(nwg % ncu), base = ncu / 8;
-        tail = static_parts ? r : ((r > base && r <= ncu / 2) ? r : base);
-        split = ncu / tail < 8 ? ncu / tail : 8;
-        if ((int64_t)tail * split * WS_FLOATS * 4 + WS_HEAD_BYTES <= workspace_bytes && ((uintptr_t)workspace & 15) == 0 && split >= 2)
+        tail = static_parts ? r : (r > base ? r : base);
+        split = (int)(slots / tail < 8 ? slots / tail : 8);
+        // (the parts of a round cut `split` ways take ceil(parts / CUs) / split of a sweep: two rounds of halves are
+        // the whole sweep again - measured: 200 items cut in two are 1 % slower than the eighth's split, 144 items cut in
+        // three 4.4 % faster)
+        if (!static_parts && (split < 2 || ((int64_t)tail * split + ncu - 1) / ncu * 10 > 9 * split)) {
+            tail = base;
+            split = (int)(slots / tail < 8 ? slots / tail : 8);
+        }
+        if (static_parts) split = ncu / tail < 8 ? ncu / tail : 8;
+        if (split >= 2 && (int64_t)tail * split <= slots)
             nwg_full = (int)nwg - tail;
         else if (workspace_required)
             return (int)hipErrorInvalidValue;       // the fixed scratch cannot hold this device's parts
         else
             split = 1, tail = 0;
+    } else if (workspace_required && workspace && nwg > ncu && slots <= 0) {
+        return (int)hipErrorInvalidValue;
     }
     const int n_parts = (int)(nwg - nwg_full) * split;
     // three part blocks per part: a die 8 % ahead of the slowest one takes about twice its round-robin share

@@ -33,8 +33,9 @@ int fp_abi_version(void);
  * cu_seqlens[s] .. cu_seqlens[s+1] (int32, device; the layout :63-77 builds), or pass NULL with nseg = 1
  * for one segment over all rows (the B == 1 branch :927-932).  max_seqlen >= the longest segment.
  * `o` may alias `q`.  o needs 8-byte alignment / stride % 4 only.  K and V must each span < 4 GiB.
- * workspace (optional, may be NULL): fp_attn_workspace_bytes() bytes of device memory, 16-byte aligned.  With
- * it, the launch's last work items (heads x 256-row query blocks; an eighth of the CUs' worth, or the partial last
+ * workspace (optional, may be NULL): fp_attn_workspace_bytes() bytes of device memory (a counter + two fp32 partial
+ * results of a query block per CU: 65 MiB on an MI355X; a smaller one is used as far as it reaches), 16-byte aligned.
+ * With it, the launch's last work items (heads x 256-row query blocks; an eighth of the CUs' worth, or the partial last
  * round) are swept as parallel KV ranges ("parts") and merged (same result to fp32 rounding), and the parts are
  * taken from a counter at the start of the workspace, so the XCDs that finish their whole sweeps first take more of
  * them (the dies of one chip differ by 7-8 % in speed); without it the call is unchanged but the launch ends with
@@ -49,7 +50,7 @@ int fp_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o,
 
 /* K1 for callers that cannot allocate or carry a workspace (HIP-graph capture, serving loops, harnesses that forbid
  * hipMalloc).  NO counterpart in the reference.  Same arguments, kernels and result as fp_attn_fwd_bf16 called with a
- * full workspace, but the split last round's fp32 partials live in a fixed device array inside the library
+ * workspace of fp_attn_static_scratch_bytes() bytes (the split follows the number of partials the workspace holds), but the split last round's fp32 partials live in a fixed device array inside the library
  * (fp_attn_static_scratch_bytes() = 256 partials = 32.5 MiB, held by every GPU the library runs on until the process
  * ends; its per-device address is looked up once per device, at the first call with that device current).  The call
  * allocates nothing.  Limit: a shape whose last round needs more than 256 partials (only possible on a device with

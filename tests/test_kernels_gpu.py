@@ -358,6 +358,34 @@ def test_attention_split_last_round_matches_unsplit_sweeps(attn_variant):
         assert rel_l2(o[lo:hi, sl], p @ v[:, sl].float()) < 5e-3, (h, lo)
 
 
+@pytest.mark.parametrize("heads", [6, 12])
+def test_attention_splits_a_nearly_full_last_round(heads):
+    """The product sequence (76 query blocks) with the 6 / 12 heads one rank of a 4- / 2-way sequence-parallel group
+    attends: 456 / 912 items = 1 / 3 full rounds + 200 / 144 items on 256 CUs.  With two partial slots per CU in the
+    workspace the 144 are cut 3 ways (an unsplit partial round would idle 112 CUs for a whole sweep; measured -4.4 %);
+    the 200 could only be cut in two, which would take a sweep again, so there the last 32 items are cut 8 ways.
+    Against the unsplit kernel (no workspace) on every row, and sampled rows against fp32 math."""
+    from framepack_amd import lib as fplib
+    S = 19385
+    g = torch.Generator(device=DEV).manual_seed(heads)
+    q, k, v = (torch.randn(S, heads * 128, generator=g, device=DEV).to(BF) for _ in range(3))
+    L = fplib.load()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert (L.fp_attn_workspace_bytes() - 256) // ((256 * 128 + 512) * 4) == 2 * ncu
+    o = ops.attention(q, k, v, heads)
+    o0 = torch.full_like(o, float("nan"))
+    fplib.check(L.fp_attn_fwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o0.data_ptr(), q.stride(0), k.stride(0),
+                                   v.stride(0), o0.stride(0), None, 1, S, S, heads, 128, 1.0 / math.sqrt(128.0), None, 0,
+                                   torch.cuda.current_stream().cuda_stream), "fp_attn_fwd_bf16")
+    assert torch.isfinite(o.float()).all() and torch.isfinite(o0.float()).all()
+    assert rel_l2(o, o0) < 2e-3
+    assert (o.float() - o0.float()).abs().max().item() < 2e-2
+    for h, lo, hi in ((heads - 1, 75 * 256, S), (heads - 1, 40 * 256, 40 * 256 + 200), (0, 0, 256)):
+        sl = slice(h * 128, (h + 1) * 128)
+        p = torch.softmax(q[lo:hi, sl].float() @ k[:, sl].float().T / math.sqrt(128.0), dim=-1)
+        assert rel_l2(o[lo:hi, sl], p @ v[:, sl].float()) < 5e-3, (h, lo)
+
+
 @pytest.mark.parametrize("layout", ["double_img", "double_txt", "single"])
 @pytest.mark.parametrize("M", [1, 300, 777])
 def test_gemm_with_k2_in_its_epilogue_is_bit_identical_to_the_two_passes(layout, M):

@@ -24,6 +24,9 @@ out = torch.empty(S, d, dtype=torch.bfloat16, device=dev)
 if os.environ.get("ATTN_VARIANT"):                     # 1: second-generation sweep, 2: third generation (default)
     from framepack_amd import lib as _fplib
     _fplib.load().fp_debug_attn_variant(int(os.environ["ATTN_VARIANT"]))
+if os.environ.get("WS_SLOTS_PER_CU") == "1":             # round 3's first policy: one partial slot per CU (a partial last
+    _full = ops._attn_workspace                         # round over half the CUs' worth then splits only an eighth)
+    ops._attn_workspace = lambda device: _full(device)[:256 + (_full(device).numel() - 256) // 2]
 attn = ops.attention_fp8 if os.environ.get("FP8") else ops.attention       # FP8=1: the e4m3 variant (quantisation included)
 AB = [int(x) for x in os.environ.get("ATTN_AB", "").split(",") if x]      # e.g. ATTN_AB=18,2: alternate the variants run by run
 for variant in range(int(os.environ.get("REPEAT", "2"))):
