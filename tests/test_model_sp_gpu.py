@@ -26,15 +26,17 @@ def _worker(rank, world, port, case, teacache, fp8_attention, heads, chunks, ret
         from framepack_amd import synthetic
         from framepack_amd.model import HunyuanVideoTransformer3DModelPacked
         bf, dev = torch.bfloat16, "cuda:0"
-        if wide:        # 13B width (24 heads x 128, mlp 12 288), one double + one single block
-            m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_13B, num_layers=1, num_single_layers=1)).to(bf)
+        if wide:        # 13B width (24 heads x 128, mlp 12 288), one double + one single block; `heads` other than 24
+            # keeps the head width and shrinks the model's (12 heads on 4 ranks = the 3 heads a rank of 8 holds)
+            m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_13B, num_layers=1, num_single_layers=1,
+                                                            num_attention_heads=heads)).to(bf)
         else:
             m = HunyuanVideoTransformer3DModelPacked(**dict(synthetic.CONFIG_TINY, num_attention_heads=heads)).to(bf)
         synthetic.init_synthetic_(dict(m.state_dict()), seed=0)
         m = m.to(dev).eval()
         if wide:
             from framepack_amd.ulysses import pick_chunks
-            assert m.heads // world == 12 and pick_chunks(19385, 12) == 2      # the overlapped two-chunk exchange
+            assert m.heads == heads and pick_chunks(19385, heads // world) == (1 if (heads // world) % 2 else 2)
         if fp8_attention:
             m.enable_fp8_attention()       # per-head scales over all rows: the same on one GPU and on a head group
         kw = synthetic.make_inputs(dtype=bf, **case)
@@ -92,15 +94,17 @@ def test_sequence_parallel_forward_equals_single_gpu(case, teacache, fp8_attenti
         assert split_is_bit_identical
 
 
-@pytest.mark.parametrize("case", ["config3", "config4"], ids=["config3_S19385", "config4_max_packed_S57785"])
-def test_sequence_parallel_forward_at_13b_width_and_product_length(case):
+@pytest.mark.parametrize("case,world,heads", [("config3", 2, 24), ("config4", 2, 24), ("config3", 4, 24), ("config3", 4, 12)],
+                         ids=["config3_S19385", "config4_max_packed_S57785", "config3_four_ranks", "config3_three_heads_per_rank"])
+def test_sequence_parallel_forward_at_13b_width_and_product_length(case, world, heads):
     """BASELINE configs 3 and 4 as far as one GPU goes: 13B-width blocks (1 double + 1 single) at S = 19 385 and at the
     longest packed sequence (window 33: S = 57 785), two ranks (12 heads each: `pick_chunks` = 2, the single block's
-    in-projection split around the exchange) against the same model's single-GPU forward.  The scaling curve itself is
-    unmeasured here (one GPU)."""
-    world = 2
+    in-projection split around the exchange) against the same model's single-GPU forward; the 4-GPU shape (6 heads per
+    rank, two chunks of 3; S = 19 385 is not a multiple of 4: the last rank's rows are padded) and, on 4 ranks with a
+    12-head model of the same head width, the 3 heads per rank (one exchange, `pick_chunks` = 1) that a rank of the 8-GPU
+    run holds.  The scaling curve itself is unmeasured here (one GPU)."""
     ret = mp.get_context("spawn").Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), CASES[case], False, False, 24, None, ret, True), nprocs=world,
+    mp.spawn(_worker, args=(world, _free_port(), CASES[case], False, False, heads, None, ret, True), nprocs=world,
              join=True)
     assert len(ret) == world
     for err, same_counts, split_is_bit_identical in ret.values():
