@@ -127,7 +127,14 @@ struct QkNormArgs {
     int rope_rows, qcol0, kcol0, width;         // q / k occupy output columns [qcol0, +width) / [kcol0, +width)
     float eps;
 };
-template <typename T, typename TO, int EPI, int AMODE, int NT = 8, int QKN = 0>
+// TALL = 1 (the VAE's Cout = 128 convolutions at full resolution): the workgroup's tile is 512 x 128 - the four waves
+// stacked, each with 128 rows x all 128 columns, i.e. the wave-level loop of NT = 8 (64 MFMAs per phase, 32 fragment
+// reads per 128 MFMAs) where the 256 x 128 tile of NT = 4 gives a wave 128 x 64 (24 reads per 64 MFMAs) and stages
+// 48 KB per 1 024 matrix cycles; this one stages 80 KB per 2 048.  LDS (all 160 KiB): wave w's A rows are private to
+// it - [w][buffer][128 rows] at w * 32 KiB - and staged by itself (8 pieces per half unit), W [buffer][128 rows] above
+// them (4 pieces per wave); the epilogue's row stage is the wave's own A-h1 half of buffer 1, which the next tile's
+// prologue does not fill (A-h1(1) is issued in the next tile's first phase, behind its barrier).
+template <typename T, typename TO, int EPI, int AMODE, int NT = 8, int QKN = 0, int TALL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A, int64_t lda, int64_t a2_delta,
                                                          int k1, const T* __restrict__ W, int64_t ldw,
                                                          const TO* __restrict__ bias, TO* __restrict__ C,
@@ -144,37 +151,50 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr int LOG2_CE = CE == 16 ? 4 : 3;       // elements per 16-byte chunk
     constexpr int KS = mfma_op<T>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A[2] 32 KiB each | W[2] | stage 32 KiB
-    constexpr unsigned W_BASE = 2 * OP_BYTES;
+    static_assert(!TALL || (NT == 8 && KS == 2 && QKN == 0 && sizeof(TO) == 2), "the tall tile: 16-bit, all 8 column tiles per wave");
+    constexpr unsigned W_BASE = TALL ? 4 * OP_BYTES : 2 * OP_BYTES;
+    constexpr unsigned A_STEP = TALL ? OP_BYTES / 2 : OP_BYTES;      // from an operand's buffer 0 to its buffer 1
+    constexpr unsigned W_STEP = TALL ? OP_BYTES / 2 : OP_BYTES;
+    constexpr int TBM = TALL ? 2 * BM : BM;                          // tile rows
+    constexpr int APW = TALL ? 8 : 4;                                // DMA pieces per wave: of an A half unit,
+    constexpr int WPW = TALL ? 4 : NT;                               // of a W unit
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = TALL ? wave : wave >> 1, wc = TALL ? 0 : wave & 1;
 
     // ---- DMA sources.  One instruction = 8 tile rows x 128 B.  A half unit = 16 instructions (4 per wave),
     //      W unit = 32 instructions (8 per wave).
     const int prow = lane >> 3, pch = lane & 7;
     // per-lane byte offsets of the DMA / load rows from the tile's first row (the tile base and the K offset are
     // wave-uniform and stay in scalar registers: the loads take the address as scalar base + 32-bit lane offset)
-    unsigned pa[2][4], pw[8];
+    unsigned pa[2][APW], pw[8];
     const char *abase = nullptr, *wbase = nullptr;
-    int arow0[2][4], wrow0[8];
+    int arow0[2][APW], wrow0[8];
+    unsigned adst[2][APW];                      // LDS offset of the piece in buffer 0 (wave-uniform)
     // AMODE 1 (convolution gather), per DMA row of the tile: coff = source of the CENTRE tap in 16-byte units from the
     // volume's start (the lane's swizzled chunk included); ccode = nine 2-bit signed voxel steps, [2 i] for the time
     // taps dt = i - 2, [6 + 2 i] for dh = i - 1, [12 + 2 i] for dw = i - 1: how far the clamped (replicate padding,
     // causal in time), stride-folded source coordinate of that tap lies from the centre's, each in {-2 .. 1}.
     // A K tile's source is then three field extracts and two multiply-adds away (uniform tap), instead of the
     // clamps, shifts and 64-bit multiplies per piece and K tile that made the gather the longest stream of the loop.
-    unsigned coff[2][4], ccode[2][4];
+    unsigned coff[2][APW], ccode[2][APW];
     int m0 = 0, n0 = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = wave * 4 + j;                                // 0..15
-            arow0[h][j] = (i >> 3) * 128 + h * 64 + (i & 7) * 8;
+        for (int j = 0; j < APW; ++j) {
+            if (TALL) {                                                // the wave's own 128 rows
+                arow0[h][j] = wave * 128 + h * 64 + j * 8;
+                adst[h][j] = (unsigned)wave * (2 * A_STEP) + (unsigned)(h * 64 + j * 8) * 128;
+            } else {
+                const int i = wave * 4 + j;                            // 0..15
+                arow0[h][j] = (i >> 3) * 128 + h * 64 + (i & 7) * 8;
+                adst[h][j] = (unsigned)arow0[h][j] * 128;
+            }
         }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wrow0[j] = (wave * NT + j) * 8;      // NT pieces per wave cover the tile's 32 NT rows of W
+    for (int j = 0; j < 8; ++j) wrow0[j] = (wave * WPW + j) * 8;     // WPW pieces per wave cover the tile's rows of W
 
     // tile order: XCD-contiguous, grouped 8 row-tiles tall so that co-running tiles share A and W panels.  The
     // workgroup is persistent: it takes tiles vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8 or
@@ -202,12 +222,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             const int t = rem / cg.band;
             tm = t * cg.tf + bnd * cg.band + (rem - t * cg.band);
         }
-        m0 = tm * BM;
-        n0 = tn * (2 * CW);
+        m0 = tm * TBM;
+        n0 = tn * (TALL ? CW : 2 * CW);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < APW; ++j) {
                 const int ar = arow0[h][j] + prow;
                 if (AMODE == 0) {
                     pa[h][j] = (unsigned)(min(m0 + ar, M - 1) - m0) * (unsigned)(lda * sizeof(T)) + (pch ^ ((ar >> 1) & 7)) * 16;
@@ -246,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // inputs to the 8-wave kernel) the tiles 2 i and 2 i + 1 share their tap: the piece's source offset is worked out
     // at the EVEN tile and kept for the odd one (poff), which halves the gather's vector instructions - a lone wave per
     // SIMD pays an issue slot for every one of them.  Which call is which is known at compile time (below).
-    unsigned poff[2][4];
+    unsigned poff[2][APW];
     auto tap_off = [&](int h, int j, int t) __attribute__((always_inline)) -> unsigned {
         const unsigned k0 = (unsigned)t * BKE;
         const unsigned tap = k0 >> cg.lcin;                                      // (uniform; tap < 27)
@@ -279,25 +299,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         if (AMODE == 1 && (FP_PROBE_NO_A_DMA == 1 || j != 0)) return;      // 1: none of them; 2: one of four (what shared W taps would leave: a third)
 #endif
         t = min(t, nk - 1);
-        dma16(src_a(h, j, t, EVEN), smem + (t & 1) * OP_BYTES + arow0[h][j] * 128);
+        dma16(src_a(h, j, t, EVEN), smem + (t & 1) * A_STEP + adst[h][j]);
     };
     auto issue_w1 = [&](int j, int t) __attribute__((always_inline)) {
         t = min(t, nk - 1);
-        dma16(src_w(j, t), smem + W_BASE + (t & 1) * OP_BYTES + wrow0[j] * 128);
+        dma16(src_w(j, t), smem + W_BASE + (t & 1) * W_STEP + wrow0[j] * 128);
     };
 
-    // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (12 + 2 NT loads per wave)
+    // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (3 APW + 2 WPW loads per wave)
     auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_a1(0, j, 0, ic<1>{});
+        for (int j = 0; j < APW; ++j) issue_a1(0, j, 0, ic<1>{});
 #pragma unroll
-        for (int j = 0; j < NT; ++j) issue_w1(j, 0);
+        for (int j = 0; j < WPW; ++j) issue_w1(j, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_a1(1, j, 0, ic<1>{});
+        for (int j = 0; j < APW; ++j) issue_a1(1, j, 0, ic<1>{});
 #pragma unroll
-        for (int j = 0; j < 4; ++j) issue_a1(0, j, 1, ic<0>{});
+        for (int j = 0; j < APW; ++j) issue_a1(0, j, 1, ic<0>{});
 #pragma unroll
-        for (int j = 0; j < NT; ++j) issue_w1(j, 1);
+        for (int j = 0; j < WPW; ++j) issue_w1(j, 1);
     };
 
     // ---- fragment read offsets (as gemm_pipeline.h)
@@ -305,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // are neighbours, and so are the two W buffers - is an instruction immediate below 64 KiB.
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        a_rd[ks] = (unsigned)(wr * 128) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
+        a_rd[ks] = (TALL ? (unsigned)wave * (2 * A_STEP) : (unsigned)(wr * 128) * 128) + (ks ? (off_k0 ^ SECOND) : off_k0);
         w_rd[ks] = W_BASE + (unsigned)(wc * CW) * 128 + (ks ? (off_k0 ^ SECOND) : off_k0);
         asm volatile("" : "+v"(a_rd[ks]), "+v"(w_rd[ks]));
     }
@@ -347,11 +367,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // new phase's first ten reads just issued - in front of the held-back MFMAs that were meant to cover their latency.
     // (The dynamic LDS segment starts at address 0: the kernel has no static LDS.)
     auto rd_a = [&](auto BUF, auto P, auto G) __attribute__((always_inline)) {
-        constexpr int off = BUF * OP_BYTES + (P * 64 + (G & 3) * 16) * 128;
+        constexpr int off = BUF * (int)A_STEP + (P * 64 + (G & 3) * 16) * 128;
         lds_read_b128<off>(af[G & (A_RING - 1)], a_rd[G >> 2]);
     };
     auto rd_w = [&](auto BUF, auto KS_, auto NI) __attribute__((always_inline)) {
-        constexpr int off = BUF * OP_BYTES + (NI * 16) * 128;
+        constexpr int off = BUF * (int)W_STEP + (NI * 16) * 128;
         if constexpr (NI < NT) lds_read_b128<off>(wf[KS_][NI], w_rd[KS_]);
     };
     // MFMA ni of group G of phase P; ZC: first K step of the tile (C operand = 0); LGKM: wait in front (-1: none)
@@ -369,12 +389,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * g4>{});
             if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * g4 + 1>{});
             if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1, ic<(BUF == 1)>{});      // t is odd in buffer 1
+            if constexpr (TALL && g < 4 && k == 6) issue_a1(1, 4 + g4, t + 1, ic<(BUF == 1)>{});
         } else {
             if constexpr (k == 2) {
                 if constexpr (g < 4) issue_a1(0, g, t + 2, ic<(BUF == 0)>{});
-                else if constexpr (g - 4 < NT) issue_w1(g - 4, t + 2);
+                else if constexpr (g - 4 < WPW) issue_w1(g - 4, t + 2);
             }
-            if constexpr (k == 5 && 2 + g < NT) issue_w1(2 + g, t + 2);
+            if constexpr (k == 5 && 2 + g < WPW) issue_w1(2 + g, t + 2);
+            if constexpr (TALL && g < 4 && k == 6) issue_a1(0, 4 + g4, t + 2, ic<(BUF == 0)>{});
         }
     };
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
@@ -383,9 +405,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // PZC (fp8 only): ZC of the PREVIOUS phase, whose held-back tiles this phase issues (in the 16-bit loop the
     // held-back groups are second K steps and never start a tile)
     auto phase = [&](auto BUF, auto P, int t, auto HAVE_PREV, auto ZC, bool relaxed, auto PZC) __attribute__((always_inline)) {
-        // younger than the unit a phase needs are always 8 + NT pieces (4 of A-h0, 4 of A-h1, NT of W)
-        if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NT + 32) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NT) : "memory");
+        // younger than the unit a phase needs are always 2 APW + WPW pieces (APW of A-h0, APW of A-h1, WPW of W)
+        static_assert(2 * APW + WPW + 32 <= 63, "vmcnt is a 6-bit counter");
+        if (relaxed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * APW + WPW + 32) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * APW + WPW) : "memory");
         __builtin_amdgcn_s_barrier();
         fence();
         if constexpr (KS == 1) {
@@ -494,7 +517,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             });
         });
       } else {
-        unsigned stage_off = 2 * BUF_BYTES + wave * 8192;      // opaque, so that the 4096 of the second stage buffer
+        // (TALL: the wave's own A-h1 half of buffer 1 - see the kernel's comment)
+        unsigned stage_off = TALL ? (unsigned)wave * (2 * A_STEP) + A_STEP + 8192u : 2 * BUF_BYTES + wave * 8192;      // opaque, so that the 4096 of the second stage buffer
         asm volatile("" : "+v"(stage_off));                    // stays an instruction immediate, not 12 more addresses
         unsigned char* stage = smem + stage_off;
         Tx4 bv[8], gv[8];
@@ -693,10 +717,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         setup(vb);
         if (AMODE == 1) {                      // (not carried across the epilogue either: phase 0 reuses tile 0's for A-h1)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) poff[1][j] = tap_off(1, j, 0);
+            for (int j = 0; j < APW; ++j) poff[1][j] = tap_off(1, j, 0);
         }
         // a ragged tile skips stores, so the relaxed count would not cover the loads: drain instead
-        if (em0 + BM > M || en0 + 2 * CW > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (em0 + TBM > M || en0 + (TALL ? CW : 2 * CW) > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         relaxed = true;
     }
 }
@@ -714,16 +738,18 @@ inline int persistent_grid() {
     return n;
 }
 
-template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8, int QKN = 0>
+template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8, int QKN = 0, int TALL = 0>
 int launch_w4(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
               void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
               const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
               const float* w_scale = nullptr, const QkNormArgs& qk = QkNormArgs{}) {
     // lane offsets inside a tile are 32-bit: 255 rows x the row stride in bytes has to fit
     if (lda >= (int64_t(1) << 22) || ldw >= (int64_t(1) << 22)) return (int)hipErrorInvalidValue;
-    const int ntm = (M + BM - 1) / BM, ntn = (N + 32 * NT - 1) / (32 * NT);
-    constexpr int smem = 2 * BUF_BYTES + 4 * 8192;        // operand buffers + the epilogue's row stage
-    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT, QKN>;
+    constexpr int TBM = TALL ? 2 * BM : BM, TBN = TALL ? 16 * NT : 32 * NT;
+    const int ntm = (M + TBM - 1) / TBM, ntn = (N + TBN - 1) / TBN;
+    // operand buffers + the epilogue's row stage (TALL: all 160 KiB are operand buffers, the stage lies inside them)
+    constexpr int smem = TALL ? 5 * OP_BYTES : 2 * BUF_BYTES + 4 * 8192;
+    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT, QKN, TALL>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     kern<<<dim3((unsigned)min(ntm * ntn, persistent_grid())), dim3(256), smem, st>>>((const T*)a, lda, a2_delta, k1, (const T*)w, ldw,

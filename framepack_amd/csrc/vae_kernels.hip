@@ -11,6 +11,7 @@
 //   * the mid-block attention (one head of 512 channels): fp32 logits of a chunk of query rows (the dense GEMM with
 //     an fp32 epilogue), frame-causal softmax into fp16 in place, P.V - the S x S matrix is never materialised.
 #include "gemm_w4.h"
+int fpi_gemm_variant();      // gemm_bf16.hip: the diagnostics switch (bit 2: no tall convolution tile)
 
 typedef _Float16 f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -59,13 +60,13 @@ extern "C" int fp_gemm_f16_f32out(const void* a, int64_t lda, const void* w, int
 // Band-major tile walk for a convolution over more than one frame (ConvGeom::band): bands of >= 16 row tiles (4 096
 // output voxels: about 1 MiB of a 128-channel input frame, three frames of it inside an XCD's 4 MiB L2) when a frame is
 // a whole number of tiles.  FRAMEPACK_CONV_BAND=0 keeps the frame-after-frame walk (diagnostics, read once).
-static void pick_band(fp_gemm::ConvGeom& cg) {
+static void pick_band(fp_gemm::ConvGeom& cg, int tile_rows) {
     static const int mode = [] { const char* e = getenv("FRAMEPACK_CONV_BAND"); return e ? atoi(e) : -1; }();
     cg.band = cg.tf = 0;
     const int64_t frame = (int64_t)cg.Ho * cg.Wo;
-    if (mode == 0 || cg.To < 2 || frame % fp_gemm::BM != 0) return;
-    const int tf = (int)(frame / fp_gemm::BM);
-    const int want = mode > 0 ? mode : 16;
+    if (mode == 0 || cg.To < 2 || frame % tile_rows != 0) return;
+    const int tf = (int)(frame / tile_rows);
+    const int want = (mode > 0 ? mode : 16) * fp_gemm::BM / tile_rows;      // (a band = 4 096 output voxels or more)
     int band = 0;
     for (int b = want; b <= tf; ++b)
         if (tf % b == 0) { band = b; break; }
@@ -78,7 +79,6 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
                        const void* resid, hipStream_t st) {
     using namespace fp_gemm;
     ConvGeom cg = cg_in;
-    pick_band(cg);
     const int64_t M64 = (int64_t)cg.To * cg.Ho * cg.Wo;
     FP_REQUIRE(M64 < (1ll << 31) && (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin < (1ll << 40));
     // centre taps are packed t << 22 | h << 11 | w in gemm_w4.h, in tap coordinates (strided: twice the output's)
@@ -94,6 +94,15 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
                       (int64_t)cg.Hi * cg.Wi < (1 << 23) &&
                       (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin * 2 / 16 < (1ll << 32);
     const bool wide = pow2 && ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
+    // Cout = 128 over at least two rounds of 512-row tiles (the last up block at full resolution): the tall tile of
+    // gemm_w4.h (512 x 128).  fp_debug_gemm_variant(1 | 4) keeps the 256 x 128 tile (diagnostics: A/B, tests).
+    const bool tall_on = (fpi_gemm_variant() & 4) == 0;
+    if (wide && tall_on && N == 128 && M64 >= 2ll * 512 * persistent_grid()) {
+        pick_band(cg, 2 * BM);
+        return resid ? launch_w4<f16, 4, 1, f16, 8, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, resid, Cout, nullptr, cg, st)
+                     : launch_w4<f16, 0, 1, f16, 8, 0, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);
+    }
+    pick_band(cg, BM);
     // Cout <= 128 / <= 32 (the last up block and conv_out): the narrow tiles of gemm_w4.h
     if (wide && N <= 32 && !resid)
         return launch_w4<f16, 0, 1, f16, 1>(x, 0, 0, K, w, K, bias, y, Cout, M, N, K, 0, nullptr, 0, nullptr, cg, st);

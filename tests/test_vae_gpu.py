@@ -97,6 +97,38 @@ def test_conv3d_causal_strided(T, H, W, cin, cout, stride):
     torch.testing.assert_close(got.float().cpu(), ref, rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("T,H,W,cin,with_res", [
+    (2, 384, 384, 128, True),        # whole 512-row tiles, one band walk (a frame = 288 tiles)
+    (3, 300, 301, 128, False),       # ragged last tile, frames that are no whole number of tiles
+    (2, 384, 400, 256, True),        # the last up block's first convolution (256 -> 128)
+])
+def test_conv3d_tall_tile_is_bit_identical_to_the_narrow_tile(T, H, W, cin, with_res):
+    """Cout = 128 over >= 2 rounds of 512-row tiles runs on the 512 x 128 tile of gemm_w4.h (TALL); with
+    fp_debug_gemm_variant(1 | 4) the same call runs on the 256 x 128 tile that the cases of test_conv3d_causal pin to
+    the oracle.  Same K order, same MFMA per output element: the same bits."""
+    from framepack_amd import lib as fplib
+    g = torch.Generator(device=DEV).manual_seed(T * H + W)
+    x = torch.randn(T, H, W, cin, generator=g, device=DEV).to(H16)
+    w = (torch.randn(128, 27 * cin, generator=g, device=DEV) * (27 * cin) ** -0.5).to(H16)
+    b = (torch.randn(128, generator=g, device=DEV) * 0.1).to(H16)
+    res = torch.randn(T, H, W, 128, generator=g, device=DEV).to(H16) if with_res else None
+    assert T * H * W >= 2 * 512 * torch.cuda.get_device_properties(0).multi_processor_count
+    tall = ops.conv3d_causal(x, w, b, resid=res)
+    old = fplib.load().fp_debug_gemm_variant(1 | 4)
+    try:
+        narrow = ops.conv3d_causal(x, w, b, resid=res)
+    finally:
+        fplib.load().fp_debug_gemm_variant(old)
+    assert torch.isfinite(tall.float()).all()
+    assert torch.equal(tall, narrow), (tall.float() - narrow.float()).abs().max().item()
+    # and a corner of the volume against fp32 math (first frame, first rows: replicate padding and the causal clamp)
+    crop = x[:, :6, :7].cpu()
+    wr = w.cpu().reshape(128, 3, 3, 3, cin).permute(0, 4, 1, 2, 3)
+    ref = ref_conv(crop, wr, b.cpu(), (1, 1, 1), None)
+    got = tall[:, :5, :6].float().cpu() - (res[:, :5, :6].float().cpu() if with_res else 0)
+    assert rel_l2(got, ref[:, :5, :6]) < 3e-3
+
+
 def test_conv3d_rejects_bad_arguments():
     x, w = rand(2, 4, 4, 32).to(DEV), rand(64, 27 * 32).to(DEV)
     with pytest.raises(ValueError):

@@ -56,4 +56,34 @@ for case in range(cases):
     if tuple(got.shape) != tuple(ref.shape) or not err < 3e-3:
         print(f"FAIL case {case}: T,H,W={T},{H},{W} cin={cin} cout={cout} {desc}: rel-L2 {err:.3e}")
         sys.exit(1)
-print(f"{cases} cases passed; worst rel-L2 {worst:.2e}")
+print(f"{cases} cases passed; worst rel-L2 {worst:.2e}", flush=True)
+
+# The 512 x 128 tile (Cout = 128 over two rounds of tiles or more, gemm_w4.h TALL) against the 256 x 128 tile that the
+# cases above pin to the oracle: the same bits (same K order per output element).  Random volumes of 270 000 - 600 000
+# voxels on the device: ragged last tiles, frames that are / are not whole tiles (the band walk), Cin 128 / 256, upsampling.
+from framepack_amd import lib as fplib  # noqa: E402
+ncu = torch.cuda.get_device_properties(0).multi_processor_count
+tall_cases = max(4, cases // 6)
+for case in range(tall_cases):
+    gd = torch.Generator(device=dev).manual_seed(1000 + case)
+    cin = rnd.choice([128, 128, 256])
+    up = rnd.choice([(1, 1, 1), (1, 1, 1), (1, 2, 2), (2, 2, 2)])
+    while True:
+        T, H, W = rnd.randint(1, 4), rnd.randint(100, 420), rnd.choice([rnd.randint(100, 420), 256, 384, 512])
+        To = 2 * T - 1 if up[0] == 2 else T
+        M = To * H * up[1] * W * up[2]
+        if 2 * 512 * ncu <= M <= 600000:
+            break
+    x = torch.randn(T, H, W, cin, generator=gd, device=dev).half()
+    wk = (torch.randn(128, 27 * cin, generator=gd, device=dev) * (27 * cin) ** -0.5).half()
+    b = (torch.randn(128, generator=gd, device=dev) * 0.1).half()
+    res = torch.randn(To, H * up[1], W * up[2], 128, generator=gd, device=dev).half() if rnd.random() < 0.5 else None
+    tall = ops.conv3d_causal(x, wk, b, up=up, resid=res)
+    old = fplib.load().fp_debug_gemm_variant(1 | 4)
+    narrow = ops.conv3d_causal(x, wk, b, up=up, resid=res)
+    fplib.load().fp_debug_gemm_variant(old)
+    if not (torch.isfinite(tall.float()).all() and torch.equal(tall, narrow)):
+        print(f"FAIL tall case {case}: T,H,W={T},{H},{W} cin={cin} up {up} resid {res is not None}: "
+              f"max diff {(tall.float() - narrow.float()).abs().max().item():.3e}")
+        sys.exit(1)
+print(f"{tall_cases} tall-tile cases bit-identical to the narrow tile")
