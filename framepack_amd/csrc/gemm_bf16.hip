@@ -50,6 +50,56 @@ extern "C" int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, 
 #undef FP_CASE
 }
 
+// Two nn.Linear of one shape over the two row segments of one activation buffer, in ONE launch: rows [0, m_split) of a
+// multiply w0 (+ bias0, gate0), rows [m_split, M) multiply w1 (+ bias1, gate1); c, resid likewise one buffer each.  The
+// double-stream blocks (ref hunyuan_video_packed.py:537-604: to_q/k/v | add_q/k/v_proj, to_out | to_add_out, ff | ff_context)
+// keep the image rows and the text rows in one buffer; the text segment alone is 4 - 16 row tiles, a launch that fills a
+// fraction of the chip for a whole tile time.  Same arithmetic per output element as two fp_gemm_bf16 calls (tiles never
+// straddle m_split): bit-identical.  Operands that do not meet the 4-wave kernel's alignment, a segment that is empty and
+// segments that would each run on the narrow tile take the two calls instead.
+extern "C" int fp_gemm_bf16_rows2(const void* a, int64_t lda, const void* w0, const void* w1, int64_t ldw,
+                                  const void* bias0, const void* bias1, void* c, int64_t ldc, int M, int m_split, int N,
+                                  int K, int epilogue, int gelu_from, const void* resid, int64_t ldr, const void* gate0,
+                                  const void* gate1, void* stream) {
+    using namespace fp_gemm;
+    FP_REQUIRE(m_split >= 0 && m_split <= M && w1 && (!bias0 == !bias1) && (!gate0 == !gate1));
+    int64_t a2_delta;
+    int k1 = 0;
+    if (int rc = check_dense(a, lda, nullptr, k1, w0, ldw, bias0, c, ldc, M, N, K, epilogue, gelu_from, resid, ldr, gate0, a2_delta))
+        return rc;
+    FP_REQUIRE(((uintptr_t)w1 & 15) == 0 && (!bias1 || ((uintptr_t)bias1 & 7) == 0) && (!gate1 || ((uintptr_t)gate1 & 7) == 0));
+    FP_REQUIRE(epilogue == 0 || epilogue == 1 || epilogue == 3);
+    if (M == 0) return 0;
+    const bool wide = ((uintptr_t)c & 15) == 0 && ldc % 8 == 0 && (epilogue < 3 || (((uintptr_t)resid & 15) == 0 && ldr % 8 == 0));
+    const int64_t tiles = ((int64_t)(m_split + BM - 1) / BM + (M - m_split + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (!(fpi_gemm_variant() & 1) || (fpi_gemm_variant() & 2) || !wide || m_split == 0 || m_split == M ||
+        tiles <= persistent_grid() / 2) {          // (variant bit 1: diagnostics - the two launches)
+        const char* a1 = (const char*)a + (int64_t)m_split * lda * 2;
+        char* c1 = (char*)c + (int64_t)m_split * ldc * 2;
+        const char* r1 = resid ? (const char*)resid + (int64_t)m_split * ldr * 2 : nullptr;
+        if (m_split > 0)
+            if (int rc = fp_gemm_bf16(a, lda, nullptr, 0, w0, ldw, bias0, c, ldc, m_split, N, K, epilogue, gelu_from, resid, ldr, gate0, stream))
+                return rc;
+        if (m_split < M)
+            return fp_gemm_bf16(a1, lda, nullptr, 0, w1, ldw, bias1, c1, ldc, M - m_split, N, K, epilogue, gelu_from, r1, ldr, gate1, stream);
+        return 0;
+    }
+    ConvGeom cg{};
+    cg.gm = K >= 8192 ? -3 : (N >= 16384 ? 2 : 8);
+    const Rows2 r2{w1, bias1, gate1, m_split};
+    hipStream_t st = (hipStream_t)stream;
+#define FP_CASE(E)                                                                                                       \
+    case E:                                                                                                              \
+        return launch_w4<bf16, E, 0, bf16, 8, 0, 0, 1>(a, lda, a2_delta, k1, w0, ldw, bias0, c, ldc, M, N, K, gelu_from, \
+                                                       resid, ldr, gate0, cg, st, nullptr, nullptr, QkNormArgs{}, r2)
+    switch (epilogue) {
+        FP_CASE(0);
+        FP_CASE(1);
+        default: FP_CASE(3);
+    }
+#undef FP_CASE
+}
+
 // The q | k | v projection of a double-stream block (epilogue 0) or the fused in-projection of a single-stream block
 // (epilogue 2: GELU from column gelu_from on) WITH K2 in its epilogue: per-head RMSNorm of the q and k columns and RoPE on
 // rows < rope_rows (gemm_w4.h, QkNormArgs) - bit-identical to fp_gemm_bf16 followed by fp_qk_rmsnorm_rope_bf16 on the same

@@ -134,15 +134,25 @@ struct QkNormArgs {
 // it - [w][buffer][128 rows] at w * 32 KiB - and staged by itself (8 pieces per half unit), W [buffer][128 rows] above
 // them (4 pieces per wave); the epilogue's row stage is the wave's own A-h1 half of buffer 1, which the next tile's
 // prologue does not fill (A-h1(1) is issued in the next tile's first phase, behind its barrier).
-template <typename T, typename TO, int EPI, int AMODE, int NT = 8, int QKN = 0, int TALL = 0>
+// GRP = 1 (the double-stream blocks' linears, ref hunyuan_video_packed.py:537-604: the image rows and the text rows of one
+// activation buffer go through two nn.Linear of the same shape): rows [0, m_split) use (W, bias, gate), rows
+// [m_split, M) use Rows2's (w2, bias2, gate2); a row tile lies in one segment (the second segment's tiles start at
+// m_split), and the text segment's 4 - 16 row tiles ride in the image segment's partly filled last round instead of
+// taking a launch - a round of a 256-CU chip - of their own.
+struct Rows2 {
+    const void *w2, *bias2, *gate2;
+    int m_split;
+};
+template <typename T, typename TO, int EPI, int AMODE, int NT = 8, int QKN = 0, int TALL = 0, int GRP = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A, int64_t lda, int64_t a2_delta,
                                                          int k1, const T* __restrict__ W, int64_t ldw,
-                                                         const TO* __restrict__ bias, TO* __restrict__ C,
+                                                         const TO* __restrict__ bias_, TO* __restrict__ C,
                                                          int64_t ldc, int M, int N, int K, int gelu_from,
                                                          const TO* __restrict__ R, int64_t ldr,
-                                                         const TO* __restrict__ gate, int ntm, int ntn, ConvGeom cg,
+                                                         const TO* __restrict__ gate_, int ntm, int ntn, ConvGeom cg,
                                                          const float* __restrict__ a_scale,
-                                                         const float* __restrict__ w_scale, QkNormArgs qk) {
+                                                         const float* __restrict__ w_scale, QkNormArgs qk, Rows2 r2) {
+    static_assert(!GRP || (AMODE == 0 && !TALL && !QKN && NT == 8 && sizeof(T) == 2), "row segments: the dense 16-bit 256 x 256 tile");
     typedef i32x4 frag_t;
     typedef TO Tx4 __attribute__((ext_vector_type(4)));
     constexpr bool SCALED = sizeof(T) == 1;
@@ -180,6 +190,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     // clamps, shifts and 64-bit multiplies per piece and K tile that made the gather the longest stream of the loop.
     unsigned coff[2][APW], ccode[2][APW];
     int m0 = 0, n0 = 0;
+    int m_end = M;                              // GRP: the end of the tile's row segment (else M)
+    const T* w_seg = W;                         // GRP: the segment's weights
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -223,6 +235,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             tm = t * cg.tf + bnd * cg.band + (rem - t * cg.band);
         }
         m0 = tm * TBM;
+        if constexpr (GRP) {
+            const int ntm0 = (r2.m_split + TBM - 1) / TBM;
+            const bool second = tm >= ntm0;
+            m0 = second ? r2.m_split + (tm - ntm0) * TBM : m0;
+            m_end = second ? M : r2.m_split;
+            w_seg = second ? reinterpret_cast<const T*>(r2.w2) : W;
+        }
         n0 = tn * (TALL ? CW : 2 * CW);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             for (int j = 0; j < APW; ++j) {
                 const int ar = arow0[h][j] + prow;
                 if (AMODE == 0) {
-                    pa[h][j] = (unsigned)(min(m0 + ar, M - 1) - m0) * (unsigned)(lda * sizeof(T)) + (pch ^ ((ar >> 1) & 7)) * 16;
+                    pa[h][j] = (unsigned)(min(m0 + ar, m_end - 1) - m0) * (unsigned)(lda * sizeof(T)) + (pch ^ ((ar >> 1) & 7)) * 16;
                 } else {
                     const int m = min(m0 + ar, M - 1);
                     const int wc = (m % cg.Wo) << cg.dw, hc = ((m / cg.Wo) % cg.Ho) << cg.dh,
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             pw[j] = (unsigned)(min(n0 + wrw, N - 1) - n0) * (unsigned)(ldw * sizeof(T)) + (pch ^ ((wrw >> 1) & 7)) * 16;
         }
         abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
-        wbase = reinterpret_cast<const char*>(W + (int64_t)n0 * ldw);
+        wbase = reinterpret_cast<const char*>(w_seg + (int64_t)n0 * ldw);
 
     };
     const int nk = K / BKE;
@@ -481,7 +500,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         asm volatile("" : "+v"(l));
         return l;
     };
+    // (GRP: the epilogue runs after the NEXT tile's setup, so the segment's terms are derived again from the tile's row)
+    auto seg_rows = [&](int em0) __attribute__((always_inline)) { return GRP ? (em0 >= r2.m_split ? M : r2.m_split) : M; };
     auto load_resid = [&](int em0, int en0, int ecw, int mi) __attribute__((always_inline)) {
+        const int M = seg_rows(em0);            // shadows the kernel's
         const int el = opaque_lane();
         const int gcol = (el & 15) * 8 < ecw ? en0 + wc * ecw + (el & 15) * 8 : N;
 #pragma unroll
@@ -492,6 +514,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         }
     };
     auto epilogue = [&](int em0, int en0, int ecw) __attribute__((always_inline)) {
+      const int M = seg_rows(em0);              // shadows the kernel's
+      const bool second = GRP && em0 >= r2.m_split;
+      const TO* const bias = second ? reinterpret_cast<const TO*>(r2.bias2) : bias_;
+      const TO* const gate = second ? reinterpret_cast<const TO*>(r2.gate2) : gate_;
       if constexpr (sizeof(TO) == 4) {
         // fp32 output (the VAE mid-block attention's logits, the DiT's fp32 head; EPI 0, optional fp32 bias): straight
         // from the accumulators, 16 B per lane - a row tile's store covers 16 rows x 64 B per instruction.  N % 4 == 0.
@@ -720,7 +746,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             for (int j = 0; j < APW; ++j) poff[1][j] = tap_off(1, j, 0);
         }
         // a ragged tile skips stores, so the relaxed count would not cover the loads: drain instead
-        if (em0 + TBM > M || en0 + (TALL ? CW : 2 * CW) > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (em0 + TBM > seg_rows(em0) || en0 + (TALL ? CW : 2 * CW) > N) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         relaxed = true;
     }
 }
@@ -738,24 +764,25 @@ inline int persistent_grid() {
     return n;
 }
 
-template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8, int QKN = 0, int TALL = 0>
+template <typename T, int EPI, int AMODE, typename TO = T, int NT = 8, int QKN = 0, int TALL = 0, int GRP = 0>
 int launch_w4(const void* a, int64_t lda, int64_t a2_delta, int k1, const void* w, int64_t ldw, const void* bias,
               void* c, int64_t ldc, int M, int N, int K, int gelu_from, const void* resid, int64_t ldr,
               const void* gate, const ConvGeom& cg, hipStream_t st, const float* a_scale = nullptr,
-              const float* w_scale = nullptr, const QkNormArgs& qk = QkNormArgs{}) {
+              const float* w_scale = nullptr, const QkNormArgs& qk = QkNormArgs{}, const Rows2& r2 = Rows2{}) {
     // lane offsets inside a tile are 32-bit: 255 rows x the row stride in bytes has to fit
     if (lda >= (int64_t(1) << 22) || ldw >= (int64_t(1) << 22)) return (int)hipErrorInvalidValue;
     constexpr int TBM = TALL ? 2 * BM : BM, TBN = TALL ? 16 * NT : 32 * NT;
-    const int ntm = (M + TBM - 1) / TBM, ntn = (N + TBN - 1) / TBN;
+    const int ntm = GRP ? (r2.m_split + TBM - 1) / TBM + (M - r2.m_split + TBM - 1) / TBM : (M + TBM - 1) / TBM;
+    const int ntn = (N + TBN - 1) / TBN;
     // operand buffers + the epilogue's row stage (TALL: all 160 KiB are operand buffers, the stage lies inside them)
     constexpr int smem = TALL ? 5 * OP_BYTES : 2 * BUF_BYTES + 4 * 8192;
-    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT, QKN, TALL>;
+    auto kern = gemm_w4_kernel<T, TO, EPI, AMODE, NT, QKN, TALL, GRP>;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     kern<<<dim3((unsigned)min(ntm * ntn, persistent_grid())), dim3(256), smem, st>>>((const T*)a, lda, a2_delta, k1, (const T*)w, ldw,
                                                               (const TO*)bias, (TO*)c, ldc, M, N, K, gelu_from,
                                                               (const TO*)resid, ldr, (const TO*)gate, ntm, ntn, cg,
-                                                              a_scale, w_scale, qk);
+                                                              a_scale, w_scale, qk, r2);
     FP_CHECK_LAUNCH();
     return 0;
 }

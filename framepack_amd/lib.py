@@ -36,6 +36,7 @@ SIGNATURES = {
     "fp_rel_l1_bf16": [P, P, L, P, P],
     "fp_gemm_bf16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_gemm_bf16_f32out": [P, L, P, L, P, P, L, I, I, I, P],
+    "fp_gemm_bf16_rows2": [P, L, P, P, L, P, P, P, L, I, I, I, I, I, I, P, L, P, P, P],
     "fp_gemm_bf16_qknorm": [P, L, P, L, P, P, L, I, I, I, I, I, P, P, P, P, P, I, I, I, I, I, F, P],
     "fp_gemm_f16": [P, L, P, I, P, L, P, P, L, I, I, I, I, I, P, L, P, P],
     "fp_debug_gemm_variant": [I],

@@ -371,6 +371,9 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         # text stream of the double blocks on a low-priority side stream (_double_block); FRAMEPACK_TEXT_OVERLAP=0: off
         self.text_stream_overlap = os.environ.get("FRAMEPACK_TEXT_OVERLAP", "1") != "0"
         self._side_streams = {}
+        # double blocks: the image and the text linear of a pair in ONE launch over the rows of the shared buffer
+        # (ops.gemm_rows2; _double_block); FRAMEPACK_GROUP_TEXT=0: separate launches (the text ones on the side stream)
+        self.group_text_gemms = os.environ.get("FRAMEPACK_GROUP_TEXT", "1") != "0"
         # K2 (RMSNorm + RoPE of q, k) in the epilogue of the GEMM that produces them (_ln_lin_qk): bit-identical, but
         # measured 0.8 % SLOWER per step than the separate pass, so off unless FRAMEPACK_FUSE_QK=1
         self.fuse_qk_norm = os.environ.get("FRAMEPACK_FUSE_QK", "0") == "1"
@@ -756,6 +759,19 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
             self._ln_lin(ws, X[Si:], csc_m, csh_m, N[Si:], e.w_ff1_c, e.b_ff1_c, out=Fh[Si:], epilogue=ops.EPI_GELU)
             self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_m)
 
+        if self._group_rows(e, Si, S):
+            # both streams' linears as one launch per pair: the text segment's 4 - 16 row tiles ride in the image
+            # segment's partly filled last round (bit-identical to the separate launches)
+            ops.layernorm_modulate(X[:Si], sc_a, sh_a, out=N[:Si])
+            ops.layernorm_modulate(X[Si:], csc_a, csh_a, out=N[Si:])
+            ops.gemm_rows2(N, Si, e.w_qkv, e.w_qkv_c, e.b_qkv, e.b_qkv_c, out=qkv)
+            self._qk_attend(q, k, v, e.nq, e.nk, rope, Si, wq_txt=e.nq_c, wk_txt=e.nk_c, normed=False)
+            ops.gemm_rows2(q, Si, e.w_out, e.w_out_c, e.b_out, e.b_out_c, out=X, epilogue=GR, resid=X, gate0=g_a, gate1=cg_a)
+            ops.layernorm_modulate(X[:Si], sc_m, sh_m, out=N[:Si])
+            ops.layernorm_modulate(X[Si:], csc_m, csh_m, out=N[Si:])
+            ops.gemm_rows2(N, Si, e.w_ff1, e.w_ff1_c, e.b_ff1, e.b_ff1_c, out=Fh, epilogue=ops.EPI_GELU)
+            ops.gemm_rows2(Fh, Si, e.w_ff2, e.w_ff2_c, e.b_ff2, e.b_ff2_c, out=X, epilogue=GR, resid=X, gate0=g_m, gate1=cg_m)
+            return
         main = torch.cuda.current_stream(X.device) if side is not None else None
         normed[0] = self._ln_lin_qk(ws, X[:Si], sc_a, sh_a, N[:Si], e.w_qkv, e.b_qkv, qkv[:Si], e.nq, e.nk, rope, Si, 0, d)
         if side is None:
@@ -785,6 +801,12 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         self._lin(ws, Fh[:Si], e.w_ff2, e.b_ff2, out=X[:Si], epilogue=GR, resid=X[:Si], gate=g_m)
         if side is None:
             self._lin(ws, Fh[Si:], e.w_ff2_c, e.b_ff2_c, out=X[Si:], epilogue=GR, resid=X[Si:], gate=cg_m)
+
+    def _group_rows(self, e, Si, S) -> bool:
+        """Whether a double block's linear pairs run as one launch each (ops.gemm_rows2): one GPU, bf16 weights (the fp8
+        GEMM has no row-segment form), both segments non-empty, K2 as its own pass."""
+        return (self.group_text_gemms and not self.sp_on and not self.fp8_compute and 0 < Si < S
+                and not isinstance(e.w_qkv, tuple) and e.w_qkv.dtype == torch.bfloat16 and not self.fuse_qk_norm)
 
     def _single_block(self, e, mod, ws, Si, S, rope):
         d, H = self.inner_dim, self.heads
@@ -824,6 +846,8 @@ class HunyuanVideoTransformer3DModelPacked(nn.Module):
         d = self.inner_dim
         o = 0
         side = self._text_side_stream(ws.X.device) if len(P.double) and S > Si else None
+        if side is not None and self._group_rows(P.double[0], Si, S):
+            side = None
         if side is not None:                        # the side stream starts behind everything queued so far
             main = torch.cuda.current_stream(ws.X.device)
             side[2].record(main)

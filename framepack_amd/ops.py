@@ -332,6 +332,40 @@ def gemm(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], ou
     return out
 
 
+def gemm_rows2(a: torch.Tensor, m_split: int, weight0: torch.Tensor, weight1: torch.Tensor,
+               bias0: Optional[torch.Tensor], bias1: Optional[torch.Tensor], out: torch.Tensor,
+               epilogue: int = EPI_BIAS, resid: Optional[torch.Tensor] = None, gate0: Optional[torch.Tensor] = None,
+               gate1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K5 over two row segments in one launch: out[:m_split] = epilogue(a[:m_split] @ weight0.T + bias0) with gate0,
+    out[m_split:] = epilogue(a[m_split:] @ weight1.T + bias1) with gate1 (the image and the text linear of a double-stream
+    block over the rows of one buffer).  Bit-identical to the two `gemm` calls.  bf16; epilogues BIAS, GELU, GATE_RESIDUAL."""
+    _dev(a, weight0, weight1, bias0, bias1, out, resid, gate0, gate1)
+    a_, M, K, lda = _rows2d(a)
+    w0_, N, K0, ldw = _rows2d(weight0)
+    w1_, N1, K1, ldw1 = _rows2d(weight1)
+    assert (N1, K1, ldw1) == (N, K0, ldw) and K0 == K and 0 <= m_split <= M
+    assert a.dtype == BF16 and weight0.dtype == BF16 and weight1.dtype == BF16 and out.dtype == BF16
+    assert (bias0 is None) == (bias1 is None) and (bias0 is None or (bias0.numel() == N and bias1.numel() == N))
+    o_, Mo, No, ldc = _rows2d(out)
+    assert (Mo, No) == (M, N)
+    if M == 0:
+        return out
+    ldr, rptr, g0, g1 = 0, None, None, None
+    if epilogue == EPI_GATE_RESIDUAL:
+        r_, Mr, Nr, ldr = _rows2d(resid)
+        assert (Mr, Nr) == (M, N) and resid.dtype == BF16
+        rptr = r_.data_ptr()
+        gate0, gate1 = gate0.reshape(-1).contiguous(), gate1.reshape(-1).contiguous()
+        assert gate0.numel() == N and gate1.numel() == N and gate0.dtype == BF16 and gate1.dtype == BF16
+        g0, g1 = gate0.data_ptr(), gate1.data_ptr()
+    else:
+        assert epilogue in (EPI_BIAS, EPI_GELU)
+    _lib.check(_lib.load().fp_gemm_bf16_rows2(a_.data_ptr(), lda, w0_.data_ptr(), w1_.data_ptr(), ldw, _ptr(bias0),
+                                              _ptr(bias1), o_.data_ptr(), ldc, M, m_split, N, K, epilogue, 0, rptr, ldr,
+                                              g0, g1, _stream(a)), "fp_gemm_bf16_rows2")
+    return out
+
+
 def gemm_f32out(a: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K5 with fp32 output: out [M,N] fp32 = a [M,K] @ weight [N,K].T + bias, a / weight bf16, bias fp32 [N] or None

@@ -146,6 +146,17 @@ int fp_gemm_bf16(const void* a, int64_t lda, const void* a2, int k1, const void*
                  const void* bias, void* c, int64_t ldc, int M, int N, int K, int epilogue, int gelu_from,
                  const void* resid, int64_t ldr, const void* gate, void* stream);
 
+/* K5 over two row segments of one activation buffer in ONE launch: rows [0, m_split) of a multiply w0 (+ bias0, gate0),
+ * rows [m_split, M) multiply w1 (+ bias1, gate1); c and resid are one buffer each, w0 and w1 have one shape and row stride.
+ * Replaces the pairs of nn.Linear of a double-stream block (hunyuan_video_packed.py:537-604 with :469-535: to_q/k/v and
+ * add_q/k/v_proj, to_out[0] and to_add_out, ff and ff_context), whose image rows and text rows this implementation keeps
+ * in one buffer: the text segment alone is 4 - 16 row tiles - a launch that fills a fraction of the chip.  Tiles never
+ * straddle m_split: bit-identical to two fp_gemm_bf16 calls (which is what runs when the operands do not meet the 4-wave
+ * kernel's 16-byte alignment or a segment is empty).  epilogue 0, 1 or 3 (as fp_gemm_bf16); both biases / gates or neither. */
+int fp_gemm_bf16_rows2(const void* a, int64_t lda, const void* w0, const void* w1, int64_t ldw, const void* bias0,
+                       const void* bias1, void* c, int64_t ldc, int M, int m_split, int N, int K, int epilogue,
+                       int gelu_from, const void* resid, int64_t ldr, const void* gate0, const void* gate1, void* stream);
+
 /* K5 with the accumulators written out in fp32: c [M, N] fp32 = a [M, K] . w [N, K]^T + bias, a and w bf16, bias fp32
  * [N] or NULL.  The output head under `high_quality_fp32_output_for_inference` (hunyuan_video_packed.py:1048-1053:
  * activations and proj_out's weights upcast to fp32, then nn.Linear; framepack/models.py:241 always sets the flag): both

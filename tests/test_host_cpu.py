@@ -107,7 +107,7 @@ def test_library_exports_every_declared_symbol():
     so = ctypes.CDLL(lib.LIB_PATH)
     for name in declared:
         assert hasattr(so, name), name
-    assert lib.load().fp_abi_version() == 4
+    assert lib.load().fp_abi_version() == 5
 
 
 def test_forward_refuses_cpu_tensors(tiny_model):

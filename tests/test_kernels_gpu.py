@@ -421,6 +421,41 @@ def test_gemm_with_k2_in_its_epilogue_is_bit_identical_to_the_two_passes(layout,
     assert torch.equal(got, want), (got.float() - want.float()).abs().max().item()
 
 
+@pytest.mark.parametrize("M,m_split,N,K", [(19385, 18400, 3072, 3072), (1500, 1100, 768, 256), (700, 300, 9216, 128),
+                                          (520, 519, 512, 64), (300, 0, 512, 64), (300, 300, 512, 64),
+                                          (600, 200, 12288, 64), (1000, 300, 8192, 128), (513, 1, 16384, 64)])
+@pytest.mark.parametrize("epi", ["bias", "gelu", "gate_residual"])
+def test_gemm_over_two_row_segments_is_bit_identical_to_two_gemms(M, m_split, N, K, epi):
+    """fp_gemm_bf16_rows2: rows [0, m_split) with (w0, bias0, gate0), rows [m_split, M) with (w1, bias1, gate1), one
+    launch (ref hunyuan_video_packed.py:537-604: the image and the text linear of a double-stream block).  Row-strided a /
+    out views (the model's q over Y), in-place residual.  Ragged tiles on both sides of the split, empty segments."""
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    abuf = torch.randn(M, K + 64, generator=g, device=DEV).to(BF)
+    a = abuf[:, :K]
+    w0, w1 = ((torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(BF) for _ in range(2))
+    b0, b1 = ((torch.randn(N, generator=g, device=DEV) * 0.1).to(BF) for _ in range(2))
+    g0, g1 = (torch.randn(N, generator=g, device=DEV).to(BF) for _ in range(2))
+    x = torch.randn(M, N + 8, generator=g, device=DEV).to(BF)
+    e = {"bias": ops.EPI_BIAS, "gelu": ops.EPI_GELU, "gate_residual": ops.EPI_GATE_RESIDUAL}[epi]
+    kw0 = dict(epilogue=e) if epi != "gate_residual" else dict(epilogue=e, gate=g0)
+    kw1 = dict(epilogue=e) if epi != "gate_residual" else dict(epilogue=e, gate=g1)
+    want = x.clone()
+    wv = want[:, :N]
+    if epi == "gate_residual":
+        kw0["resid"], kw1["resid"] = wv[:m_split], wv[m_split:]
+    ops.gemm(a[:m_split], w0, b0, out=wv[:m_split], **kw0)
+    ops.gemm(a[m_split:], w1, b1, out=wv[m_split:], **kw1)
+    got = x.clone()
+    gv = got[:, :N]
+    ops.gemm_rows2(a, m_split, w0, w1, b0, b1, out=gv, epilogue=e, resid=gv if epi == "gate_residual" else None,
+                   gate0=g0 if epi == "gate_residual" else None, gate1=g1 if epi == "gate_residual" else None)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(got, want)
+    if epi == "bias" and M <= 1500:
+        ref = torch.cat([a[:m_split].float() @ w0.float().T + b0.float(), a[m_split:].float() @ w1.float().T + b1.float()])
+        assert rel_l2(gv, ref) < 4e-3
+
+
 def test_layernorm_affine_matches_torch_layer_norm():
     """K3's affine form (the token refiner's nn.LayerNorm, ref hunyuan_video_packed.py:264, 273 through
     dit_common.py:9-10): fp32 arithmetic, one rounding - against F.layer_norm in fp32 on the same bf16 values."""

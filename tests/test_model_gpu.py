@@ -383,6 +383,7 @@ def test_text_stream_on_the_side_stream_changes_nothing(tiny):
     GEMMs run for multiple rounds while the text ones queue beside them (a missing join shows up here)."""
     m, _ = tiny
     assert m.text_stream_overlap and m._text_side_stream(torch.device(DEV)) is not None
+    m.group_text_gemms = False           # (the default - one launch per pair of linears - leaves the side stream idle)
     for case in ("config1", "odd_bucket_pad", "max_text_tail"):
         kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES[case]))
         m.text_stream_overlap = False
@@ -394,9 +395,11 @@ def test_text_stream_on_the_side_stream_changes_nothing(tiny):
     m.taps = {}
     assert m._text_side_stream(torch.device(DEV)) is None
     m.taps = None
+    m.group_text_gemms = True
 
     cfg_kw = dict(synthetic.CONFIG_13B, num_layers=3, num_single_layers=1)
     big, _ = build(cfg_kw, seed=2)
+    big.group_text_gemms = False
     kw = to_dev(synthetic.make_inputs(dtype=BF, seed=11, frames_latent=9, height=320, width=320, n_text=256, sigma=0.6))
     big.text_stream_overlap = False
     want = big(return_dict=False, **kw)[0].clone()
@@ -404,8 +407,29 @@ def test_text_stream_on_the_side_stream_changes_nothing(tiny):
     for _ in range(3):
         got = big(return_dict=False, **kw)[0]
         assert torch.isfinite(got.float()).all() and torch.equal(got, want)
+    # the default: each pair of linears (image rows | text rows) as ONE launch (ops.gemm_rows2) - the same bits again
+    big.group_text_gemms = True
+    assert big._group_rows(big._packed.double[0], 100, 200)
+    for _ in range(2):
+        assert torch.equal(big(return_dict=False, **kw)[0], want)
     del big
     torch.cuda.empty_cache()
+
+
+def test_linear_pairs_of_the_double_blocks_in_one_launch_change_nothing(tiny):
+    """model.group_text_gemms (default): the image and the text linear of a double block as one launch over the rows of
+    the shared buffer.  Tiles never straddle the two segments, so the result is BIT-identical to separate launches."""
+    m, _ = tiny
+    assert m.group_text_gemms
+    for case in ("config1", "odd_bucket_pad", "max_text_tail"):
+        kw = to_dev(synthetic.make_inputs(dtype=BF, **CASES[case]))
+        m.group_text_gemms = False
+        m.text_stream_overlap = False
+        want = m(return_dict=False, **kw)[0].clone()
+        m.group_text_gemms = True
+        m.text_stream_overlap = True
+        for _ in range(2):
+            assert torch.equal(m(return_dict=False, **kw)[0], want), case
 
 
 def test_k2_in_the_gemm_epilogue_changes_nothing(tiny):

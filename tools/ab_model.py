@@ -1,7 +1,8 @@
 """Same-process A/B of kernel generations inside the 13B forward (ms per forward, alternating).
 usage: ab_model.py [gemm|attn] [fp8]      (fp8: the opt-in e4m3 mode, linears and attention)
 AB_VARIANTS=3,1 (env): the two values handed to the fp_debug_*_variant switch instead of 0, 1
-(gemm: 3 = static tile schedule, 1 = tiles from the counters; attn: 18 = one block per part, 2 = parts from the counter)"""
+(gemm: 3 = static tile schedule, 1 = tiles from the counters; attn: 18 = one block per part, 2 = parts from the counter)
+AB_ATTR=group_text_gemms (env): alternate a boolean attribute of the model (False, True) instead of a library switch"""
 import os
 import sys
 import time
@@ -27,13 +28,18 @@ L = lib.load()
 with torch.inference_mode():
     for _ in range(2):
         model(return_dict=False, **kw)
+    attr = os.environ.get("AB_ATTR")
     for rep in range(3):
-        for v in [int(x) for x in os.environ.get("AB_VARIANTS", "0,1").split(",")]:
-            (L.fp_debug_attn_variant if (len(sys.argv) > 1 and sys.argv[1] == "attn") else L.fp_debug_gemm_variant)(v)
+        for v in ([0, 1] if attr else [int(x) for x in os.environ.get("AB_VARIANTS", "0,1").split(",")]):
+            if attr:
+                assert isinstance(getattr(model, attr), bool)
+                setattr(model, attr, bool(v))
+            else:
+                (L.fp_debug_attn_variant if (len(sys.argv) > 1 and sys.argv[1] == "attn") else L.fp_debug_gemm_variant)(v)
             model(return_dict=False, **kw)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(3):
                 out = model(return_dict=False, **kw)[0]
             torch.cuda.synchronize()
-            print(f"rep {rep} {sys.argv[1] if len(sys.argv) > 1 else 'gemm'} variant {v}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)
+            print(f"rep {rep} {attr or (sys.argv[1] if len(sys.argv) > 1 else 'gemm')} variant {v}: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per forward", flush=True)
