@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr int BKE = 128 / (int)sizeof(T);
     constexpr int CE = 16 / (int)sizeof(T);
     constexpr int LOG2_CE = CE == 16 ? 4 : 3;       // elements per 16-byte chunk
+    constexpr int LOG2_TB = sizeof(T) == 1 ? 0 : 1;  // log2 of an element's bytes
     constexpr int KS = mfma_op<T>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A[2] 32 KiB each | W[2] | stage 32 KiB
     static_assert(!TALL || (NT == 8 && KS == 2 && QKN == 0 && sizeof(TO) == 2), "the tall tile: 16-bit, all 8 column tiles per wave");
@@ -182,8 +183,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     const char *abase = nullptr, *wbase = nullptr;
     int arow0[2][APW], wrow0[8];
     unsigned adst[2][APW];                      // LDS offset of the piece in buffer 0 (wave-uniform)
-    // AMODE 1 (convolution gather), per DMA row of the tile: coff = source of the CENTRE tap in 16-byte units from the
-    // volume's start (the lane's swizzled chunk included); ccode = nine 2-bit signed voxel steps, [2 i] for the time
+    // AMODE 1 (convolution gather), per DMA row of the tile: coff = source of the CENTRE tap in BYTES from the tile's
+    // scalar base `abase` (= the start of the earliest frame any tap of the tile's first row reads: every source of the
+    // tile lies at or behind it, within 32 bits - the launcher checks; the lane's swizzled chunk included), so that a
+    // piece's address is scalar base + 32-bit lane offset like the dense operand's: no 64-bit vector arithmetic per piece; ccode = nine 2-bit signed voxel steps, [2 i] for the time
     // taps dt = i - 2, [6 + 2 i] for dh = i - 1, [12 + 2 i] for dw = i - 1: how far the clamped (replicate padding,
     // causal in time), stride-folded source coordinate of that tap lies from the centre's, each in {-2 .. 1}.
     // A K tile's source is then three field extracts and two multiply-adds away (uniform tap), instead of the
@@ -243,6 +246,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             w_seg = second ? reinterpret_cast<const T*>(r2.w2) : W;
         }
         n0 = tn * (TALL ? CW : 2 * CW);
+        int lo_vox = 0;                             // AMODE 1: first voxel of the frame the tile's earliest tap reads (uniform)
+        if (AMODE == 1) {
+            const int tc = (m0 / (cg.Wo * cg.Ho)) << cg.dt, x = max(tc - 2, 0);
+            lo_vox = (cg.st ? ((x + 1) >> 1) : x) * (cg.Hi * cg.Wi);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     ccode[h][j] = code;
                     // the row's swizzle term is (prow >> 1) | 4 (j & 1)  (rows come 8 per instruction)
                     const unsigned chunk = (unsigned)(pch ^ (prow >> 1) ^ ((j & 1) << 2));
-                    coff[h][j] = ((unsigned)((t0 * cg.Hi + h0) * cg.Wi + w0) << (cg.lcin - LOG2_CE)) + chunk;
+                    coff[h][j] = ((unsigned)((t0 * cg.Hi + h0) * cg.Wi + w0 - lo_vox) << (cg.lcin + LOG2_TB)) + chunk * 16;
                 }
             }
 #pragma unroll
@@ -276,7 +284,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
             const int wrw = wrow0[j] + prow;
             pw[j] = (unsigned)(min(n0 + wrw, N - 1) - n0) * (unsigned)(ldw * sizeof(T)) + (pch ^ ((wrw >> 1) & 7)) * 16;
         }
-        abase = reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
+        abase = AMODE == 1 ? reinterpret_cast<const char*>(A) + ((int64_t)lo_vox << (cg.lcin + LOG2_TB))
+                           : reinterpret_cast<const char*>(A + (int64_t)m0 * lda);
         wbase = reinterpret_cast<const char*>(w_seg + (int64_t)n0 * ldw);
 
     };
@@ -295,7 +304,31 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         const int dT = __builtin_amdgcn_sbfe(code, 2 * it, 2), dH = __builtin_amdgcn_sbfe(code, 6 + 2 * ih, 2),
                   dW = __builtin_amdgcn_sbfe(code, 12 + 2 * iw, 2);
         const int dvox = __mul24(dT, cg.Hi * cg.Wi) + __mul24(dH, cg.Wi) + dW;
-        return coff[h][j] + ((unsigned)dvox << (cg.lcin - LOG2_CE));
+        return coff[h][j] + ((unsigned)dvox << (cg.lcin + LOG2_TB));
+    };
+    // The same offset in two halves of three vector instructions each, for the main loop: a lone wave per SIMD issues
+    // one instruction per ~4 cycles, so whatever stands between two MFMAs beyond ~3 instructions idles the matrix pipe
+    // (16 cycles per MFMA); worked out in one place, a piece's offset + its issue were 10 - 12 instructions.  The halves
+    // go to the two MFMA gaps in front of the piece's own (`slot`).  tap_bits: the tap's bit positions in ccode (uniform,
+    // once per phase).
+    int tapT = 0, tapH = 0, tapW = 0;
+    unsigned ptmp = 0;
+    auto tap_bits = [&](int t) __attribute__((always_inline)) {
+        t = min(t, nk - 1);
+        const unsigned tap = ((unsigned)t * BKE) >> cg.lcin;
+        const unsigned t3 = (tap * 11u) >> 5, it = (tap * 57u) >> 9;
+        tapT = (int)(2 * it);
+        tapH = (int)(6 + 2 * (t3 - 3u * it));
+        tapW = (int)(12 + 2 * (tap - 3u * t3));
+    };
+    auto prep_a = [&](auto PART, int h, int j) __attribute__((always_inline)) {
+        const int code = (int)ccode[h][j];
+        if constexpr (PART == 0) {
+            ptmp = (unsigned)(__mul24(__builtin_amdgcn_sbfe(code, tapH, 2), cg.Wi) + __builtin_amdgcn_sbfe(code, tapW, 2));
+        } else {
+            const int dvox = __mul24(__builtin_amdgcn_sbfe(code, tapT, 2), cg.Hi * cg.Wi) + (int)ptmp;
+            poff[h][j] = coff[h][j] + ((unsigned)dvox << (cg.lcin + LOG2_TB));
+        }
     };
     auto src_a = [&](int h, int j, int t, auto EVEN) __attribute__((always_inline)) -> const T* {
         if (AMODE == 0) {
@@ -305,7 +338,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         } else {
             const unsigned c0 = ((unsigned)t * BKE) & (unsigned)(cg.Cin - 1);        // (uniform)
             if constexpr (EVEN) poff[h][j] = tap_off(h, j, t);
-            return reinterpret_cast<const T*>(reinterpret_cast<const char*>(A + c0) + ((uint64_t)poff[h][j] << 4));
+            asm volatile("" : "+v"(poff[h][j]));    // (as above: scalar base + 32-bit lane offset)
+            return reinterpret_cast<const T*>(abase + (int64_t)(c0 * sizeof(T)) + poff[h][j]);
         }
     };
     auto src_w = [&](int j, int t) __attribute__((always_inline)) -> const T* {
@@ -313,30 +347,36 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         return reinterpret_cast<const T*>(wbase + (int64_t)t * (BKE * (int)sizeof(T)) + pw[j]);
     };
     // EVEN: t is even before the clamp (clamped, an even and the odd call behind it both name tile nk - 1)
-    auto issue_a1 = [&](int h, int j, int t, auto EVEN) __attribute__((always_inline)) {
+    // PAR (main loop of the gather, AMODE 1): the destination buffer as the compile-time parity of the UNCLAMPED tile
+    // index - a load past the last K tile then lands in the buffer that tile would have used, which nobody reads any
+    // more (its last reader finished behind the previous barrier; W fragments are in registers) - so the LDS address
+    // is base + immediate instead of three scalar instructions on the clamped index.  -1: the clamped index's parity.
+    auto issue_a1 = [&](int h, int j, int t, auto EVEN, auto PAR) __attribute__((always_inline)) {
 #if defined(FP_PROBE_NO_A_DMA)      // timing-only probe builds (results wrong): what the A operand's LDS-DMA pieces cost
         if (AMODE == 1 && (FP_PROBE_NO_A_DMA == 1 || j != 0)) return;      // 1: none of them; 2: one of four (what shared W taps would leave: a third)
 #endif
         t = min(t, nk - 1);
-        dma16(src_a(h, j, t, EVEN), smem + (t & 1) * A_STEP + adst[h][j]);
+        const unsigned par = decltype(PAR)::value >= 0 ? (unsigned)decltype(PAR)::value : (unsigned)(t & 1);
+        dma16(src_a(h, j, t, EVEN), smem + par * A_STEP + adst[h][j]);
     };
-    auto issue_w1 = [&](int j, int t) __attribute__((always_inline)) {
+    auto issue_w1 = [&](int j, int t, auto PAR) __attribute__((always_inline)) {
         t = min(t, nk - 1);
-        dma16(src_w(j, t), smem + W_BASE + (t & 1) * W_STEP + wrow0[j] * 128);
+        const unsigned par = decltype(PAR)::value >= 0 ? (unsigned)decltype(PAR)::value : (unsigned)(t & 1);
+        dma16(src_w(j, t), smem + W_BASE + par * W_STEP + wrow0[j] * 128);
     };
 
     // the order the counted waits assume: A-h0(0), W(0) | A-h1(0) | A-h0(1), W(1)   (3 APW + 2 WPW loads per wave)
     auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < APW; ++j) issue_a1(0, j, 0, ic<1>{});
+        for (int j = 0; j < APW; ++j) issue_a1(0, j, 0, ic<1>{}, ic<-1>{});
 #pragma unroll
-        for (int j = 0; j < WPW; ++j) issue_w1(j, 0);
+        for (int j = 0; j < WPW; ++j) issue_w1(j, 0, ic<-1>{});
 #pragma unroll
-        for (int j = 0; j < APW; ++j) issue_a1(1, j, 0, ic<1>{});
+        for (int j = 0; j < APW; ++j) issue_a1(1, j, 0, ic<1>{}, ic<-1>{});
 #pragma unroll
-        for (int j = 0; j < APW; ++j) issue_a1(0, j, 1, ic<0>{});
+        for (int j = 0; j < APW; ++j) issue_a1(0, j, 1, ic<0>{}, ic<-1>{});
 #pragma unroll
-        for (int j = 0; j < WPW; ++j) issue_w1(j, 1);
+        for (int j = 0; j < WPW; ++j) issue_w1(j, 1, ic<-1>{});
     };
 
     // ---- fragment read offsets (as gemm_pipeline.h)
@@ -404,18 +444,30 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         constexpr int g = G, k = K_;
         constexpr int g4 = g < 4 ? g : 0;
         if constexpr (k == 0 && g + A_AHEAD < 8) rd_a(BUF, P, ic<g + A_AHEAD>{});
+        // AMODE 1: the gathered pieces' offsets are due when the tile they load is an even one (t + 1 in buffer 1's P0,
+        // t + 2 in buffer 0's P1); their two halves go to the gaps in front of the piece's
+        constexpr bool PREP = AMODE == 1 && ((P == 0 && BUF == 1) || (P == 1 && BUF == 0));
+        constexpr int PAR1 = AMODE == 1 ? 1 - BUF : -1, PAR2 = AMODE == 1 ? (int)BUF : -1;      // buffers of tiles t + 1, t + 2
         if constexpr (P == 0) {
             if constexpr (g < 4 && k == 1) rd_w(BUF, ic<1>{}, ic<2 * g4>{});
             if constexpr (g < 4 && k == 2) rd_w(BUF, ic<1>{}, ic<2 * g4 + 1>{});
-            if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1, ic<(BUF == 1)>{});      // t is odd in buffer 1
-            if constexpr (TALL && g < 4 && k == 6) issue_a1(1, 4 + g4, t + 1, ic<(BUF == 1)>{});
+            if constexpr (PREP && g < 4 && k == 1) prep_a(ic<0>{}, 1, g4);
+            if constexpr (PREP && g < 4 && k == 2) prep_a(ic<1>{}, 1, g4);
+            if constexpr (PREP && TALL && g < 4 && k == 3) prep_a(ic<0>{}, 1, 4 + g4);
+            if constexpr (PREP && TALL && g < 4 && k == 5) prep_a(ic<1>{}, 1, 4 + g4);
+            if constexpr (g < 4 && k == 4) issue_a1(1, g, t + 1, ic<0>{}, ic<PAR1>{});
+            if constexpr (TALL && g < 4 && k == 6) issue_a1(1, 4 + g4, t + 1, ic<0>{}, ic<PAR1>{});
         } else {
+            if constexpr (PREP && g < 4 && k == 0) prep_a(ic<0>{}, 0, g4);
+            if constexpr (PREP && g < 4 && k == 1) prep_a(ic<1>{}, 0, g4);
+            if constexpr (PREP && TALL && g < 4 && k == 3) prep_a(ic<0>{}, 0, 4 + g4);
+            if constexpr (PREP && TALL && g < 4 && k == 4) prep_a(ic<1>{}, 0, 4 + g4);
             if constexpr (k == 2) {
-                if constexpr (g < 4) issue_a1(0, g, t + 2, ic<(BUF == 0)>{});
-                else if constexpr (g - 4 < WPW) issue_w1(g - 4, t + 2);
+                if constexpr (g < 4) issue_a1(0, g, t + 2, ic<0>{}, ic<PAR2>{});
+                else if constexpr (g - 4 < WPW) issue_w1(g - 4, t + 2, ic<PAR2>{});
             }
-            if constexpr (k == 5 && 2 + g < WPW) issue_w1(2 + g, t + 2);
-            if constexpr (TALL && g < 4 && k == 6) issue_a1(0, 4 + g4, t + 2, ic<(BUF == 0)>{});
+            if constexpr (k == 5 && 2 + g < WPW) issue_w1(2 + g, t + 2, ic<PAR2>{});
+            if constexpr (TALL && g < 4 && k == 6) issue_a1(0, 4 + g4, t + 2, ic<0>{}, ic<PAR2>{});
         }
     };
     auto fence = []() __attribute__((always_inline)) { __builtin_amdgcn_sched_barrier(0); };
@@ -452,13 +504,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
                     fence();
                     if constexpr (P == 0) {
                         if constexpr (mi == 0) rd_w8(BUF, ic<n + 2>{});
-                        if constexpr (mi == 2 && n < 4) issue_a1(1, n, t + 1, ic<(BUF == 1)>{});
+                        if constexpr (mi == 2 && n < 4) issue_a1(1, n, t + 1, ic<(BUF == 1)>{}, ic<-1>{});
                     } else {
                         if constexpr (mi == 0) {
-                            if constexpr (n < 4) issue_a1(0, n, t + 2, ic<(BUF == 0)>{});
-                            else issue_w1(n - 4, t + 2);
+                            if constexpr (n < 4) issue_a1(0, n, t + 2, ic<(BUF == 0)>{}, ic<-1>{});
+                            else issue_w1(n - 4, t + 2, ic<-1>{});
                         }
-                        if constexpr (mi == 2) issue_w1(2 + n, t + 2);
+                        if constexpr (mi == 2) issue_w1(2 + n, t + 2, ic<-1>{});
                     }
                     fence();
                 });
@@ -467,6 +519,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         } else {
             if constexpr (P == 0) static_for<8>([&](auto ni) __attribute__((always_inline)) { rd_w(BUF, ic<0>{}, ni); });
             static_for<A_AHEAD>([&](auto g) __attribute__((always_inline)) { rd_a(BUF, P, g); });
+            if constexpr (AMODE == 1 && P == 0 && BUF == 1) tap_bits(t + 1);
+            if constexpr (AMODE == 1 && P == 1 && BUF == 0) tap_bits(t + 2);
             fence();
             if constexpr (HAVE_PREV) {      // the two groups the previous phase left behind (fragments long landed)
                 static_for<8>([&](auto ni) __attribute__((always_inline)) { mfma1(ic<1 - P>{}, ic<6>{}, ni, ic<0>{}, ic<-1>{}); });

@@ -87,12 +87,14 @@ static int conv_launch(const void* x, const void* w, const void* bias, void* y, 
     FP_REQUIRE((int64_t)((M + BM - 1) / BM) * ((N + 31) / 32) < (1ll << 31));
     // the 4-wave kernel's gather needs Cin to be a power of two (voxel steps become shifts) of at least two K tiles
     // (128 channels: K tiles 2 i and 2 i + 1 then share their tap, and the odd one reuses the even one's source offsets),
-    // 24-bit multiplies of the plane and row pitch in voxels, and sources addressable in 16-byte units from the volume's
-    // start; anything else (and outputs aligned to 8 bytes only) runs on the 8-wave kernel, which computes every source
-    // from coordinates
+    // 24-bit multiplies of the plane and row pitch in voxels, and every source of a tile within 4 GiB of the tile's base
+    // (the start of the frame its earliest tap reads: a tile's 512 rows span 512 / (Ho Wo) + 2 output frames at most,
+    // twice as many input frames under a temporal stride, and the taps reach two frames back); anything else (and
+    // outputs aligned to 8 bytes only) runs on the 8-wave kernel, which computes every source from coordinates
+    const int64_t tile_frames = 2 * (512 / ((int64_t)cg.Ho * cg.Wo) + 2) + 4;
     const bool pow2 = (cg.Cin & (cg.Cin - 1)) == 0 && cg.Cin >= 2 * BK && cg.lcin == __builtin_ctz((unsigned)cg.Cin) &&
-                      (int64_t)cg.Hi * cg.Wi < (1 << 23) &&
-                      (int64_t)cg.Ti * cg.Hi * cg.Wi * cg.Cin * 2 / 16 < (1ll << 32);
+                      (int64_t)cg.Hi * cg.Wi < (1 << 23) && (int64_t)cg.Ti * cg.Hi * cg.Wi < (1ll << 31) &&
+                      tile_frames * cg.Hi * cg.Wi * cg.Cin * 2 < (1ll << 32);
     const bool wide = pow2 && ((uintptr_t)y & 15) == 0 && (!resid || ((uintptr_t)resid & 15) == 0);      // Cout % 8 == 0
     // Cout = 128 over at least two rounds of 512-row tiles (the last up block at full resolution): the tall tile of
     // gemm_w4.h (512 x 128).  fp_debug_gemm_variant(1 | 4) keeps the 256 x 128 tile (diagnostics: A/B, tests).
