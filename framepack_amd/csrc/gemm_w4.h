@@ -158,7 +158,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     constexpr bool SCALED = sizeof(T) == 1;
     constexpr int BKE = 128 / (int)sizeof(T);
     constexpr int CE = 16 / (int)sizeof(T);
-    constexpr int LOG2_CE = CE == 16 ? 4 : 3;       // elements per 16-byte chunk
     constexpr int LOG2_TB = sizeof(T) == 1 ? 0 : 1;  // log2 of an element's bytes
     constexpr int KS = mfma_op<T>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A[2] 32 KiB each | W[2] | stage 32 KiB
@@ -347,6 +346,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         return reinterpret_cast<const T*>(wbase + (int64_t)t * (BKE * (int)sizeof(T)) + pw[j]);
     };
     // EVEN: t is even before the clamp (clamped, an even and the odd call behind it both name tile nk - 1)
+#if defined(FP_PROBE_REG_LOAD)
+    i32x4 probe_sink = {0, 0, 0, 0};
+#endif
     // PAR (main loop of the gather, AMODE 1): the destination buffer as the compile-time parity of the UNCLAMPED tile
     // index - a load past the last K tile then lands in the buffer that tile would have used, which nobody reads any
     // more (its last reader finished behind the previous barrier; W fragments are in registers) - so the LDS address
@@ -355,11 +357,34 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
 #if defined(FP_PROBE_NO_A_DMA)      // timing-only probe builds (results wrong): what the A operand's LDS-DMA pieces cost
         if (AMODE == 1 && (FP_PROBE_NO_A_DMA == 1 || j != 0)) return;      // 1: none of them; 2: one of four (what shared W taps would leave: a third)
 #endif
+#if defined(FP_PROBE_NO_DMA)        // the same for the dense operands (mask: 1 = no A pieces, 2 = no W pieces)
+        if (AMODE == 0 && (FP_PROBE_NO_DMA & 1)) return;
+#endif
+#if defined(FP_PROBE_REG_LOAD)      // timing only: the same loads into registers (never stored to LDS) instead of LDS-DMA
+        if (AMODE == 0) {
+            t = min(t, nk - 1);
+            const int64_t koff = (int64_t)t * BKE + ((t * BKE >= k1) ? a2_delta : 0);
+            const char* sb = abase + koff * (int64_t)sizeof(T);
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(probe_sink) : "v"(pa[h][j]), "s"(sb));
+            return;
+        }
+#endif
         t = min(t, nk - 1);
         const unsigned par = decltype(PAR)::value >= 0 ? (unsigned)decltype(PAR)::value : (unsigned)(t & 1);
         dma16(src_a(h, j, t, EVEN), smem + par * A_STEP + adst[h][j]);
     };
     auto issue_w1 = [&](int j, int t, auto PAR) __attribute__((always_inline)) {
+#if defined(FP_PROBE_NO_DMA)
+        if (AMODE == 0 && (FP_PROBE_NO_DMA & 2)) return;
+#endif
+#if defined(FP_PROBE_REG_LOAD)
+        if (AMODE == 0) {
+            t = min(t, nk - 1);
+            const char* sb = wbase + (int64_t)t * (BKE * (int)sizeof(T));
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(probe_sink) : "v"(pw[j]), "s"(sb));
+            return;
+        }
+#endif
         t = min(t, nk - 1);
         const unsigned par = decltype(PAR)::value >= 0 ? (unsigned)decltype(PAR)::value : (unsigned)(t & 1);
         dma16(src_w(j, t), smem + W_BASE + par * W_STEP + wrow0[j] * 128);
@@ -791,6 +816,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
         fence();
         asm volatile("s_nop 15\ns_nop 15" ::: "memory");        // the last MFMAs retire before their tiles are read
         epilogue(em0, en0, ecw);
+#if defined(FP_PROBE_REG_LOAD)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" ::"v"(probe_sink));
+#endif
         if (!more) break;
         // the operand pointers are recomputed rather than kept across the epilogue (32 VGPRs it needs itself)
         asm volatile("" : "+s"(vb));
