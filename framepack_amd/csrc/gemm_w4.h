@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(const T* __restrict__ A
     typedef TO Tx4 __attribute__((ext_vector_type(4)));
     constexpr bool SCALED = sizeof(T) == 1;
     constexpr int BKE = 128 / (int)sizeof(T);
-    constexpr int CE = 16 / (int)sizeof(T);
     constexpr int LOG2_TB = sizeof(T) == 1 ? 0 : 1;  // log2 of an element's bytes
     constexpr int KS = mfma_op<T>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // A[2] 32 KiB each | W[2] | stage 32 KiB
