@@ -265,7 +265,8 @@ int fp_softmax_framecausal_f32_f16(void* s, int rows, int cols, int64_t ld, int 
  * 2's schedule; the default takes the parts from a counter).  v < 0 only queries.  Returns the previous value.  Process-wide; the
  * switches are atomics read once per launch, so a change never tears a launch in flight on another thread.
  * fp_gemm_fp8_bf16 follows the GEMM switch too.  For the GEMM, v >> 4 (when non-zero) overrides the number of row
- * tiles per group of the tile walk (tools/gemm_xp.py scans it: FP_GEMM_VARIANT = 1 + 16 * gm). */
+ * tiles per group of the tile walk (tools/gemm_xp.py scans it: FP_GEMM_VARIANT = 1 + 16 * gm); + 2: fp_gemm_bf16_rows2
+ * runs its two segments as two launches; + 4: the Cout = 128 convolutions keep the 256 x 128 tile (default: 512 x 128). */
 int fp_debug_gemm_variant(int v);
 int fp_debug_attn_variant(int v);
 
